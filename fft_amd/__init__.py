@@ -1,0 +1,10 @@
+"""fft_amd — MI355X (gfx950) native numeric core for the Gecesars/FFT analyzer hot path.
+
+Host side is a thin ctypes layer over fft_amd/libspecengine.so (C ABI: include/specengine.h).
+`fft_amd.specengine` mirrors the reference's analysis interface (calculate_fft / compute /
+dominant_peak, reference main.py:452-479, 959-965, 1029, 1622-1629).
+"""
+from . import _lib  # noqa: F401
+from .batch import rfft_peak, window_id  # noqa: F401
+
+__all__ = ["rfft_peak", "window_id"]

@@ -1,0 +1,116 @@
+"""ctypes binding of libspecengine.so (the C ABI declared in include/specengine.h).
+
+No torch, no numpy-side compute: this module only loads the shared library, declares the
+prototypes and turns negative status codes into the exceptions the reference's GUI already
+catches (ValueError for bad input -> main.py:531; RuntimeError otherwise -> main.py:485).
+There is no CPU fallback: if the library is missing, importing compute entry points fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspecengine.so")
+
+SA_OK, SA_EINVAL, SA_ENODEV, SA_EHIP, SA_ENOMEM, SA_EUNSUP = 0, -1, -2, -3, -4, -5
+
+WIN_NONE, WIN_HANN, WIN_HAMMING, WIN_BLACKMAN, WIN_GAUSSIAN = 0, 1, 2, 3, 4
+WINDOW_IDS = {None: 0, "none": 0, "rect": 0, "boxcar": 0, "hann": 1, "hanning": 1, "hamming": 2,
+              "blackman": 3, "gaussian": 4, "gauss": 4}
+F_WRITE_MAG, F_DB, F_EXCLUDE_DC_NYQ = 1, 2, 4
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/specengine.h declares must be listed here
+# (tests/test_abi.py checks header <-> this table <-> the .so exports).
+_vp, _i32, _i64, _u64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+PROTOTYPES = {
+    "sa_init": (C.c_int, [C.c_int]),
+    "sa_shutdown": (None, []),
+    "sa_device_count": (C.c_int, []),
+    "sa_set_device": (C.c_int, [C.c_int]),
+    "sa_last_error": (C.c_char_p, []),
+    "sa_version": (C.c_char_p, []),
+    "sa_dev_alloc": (C.c_int, [C.POINTER(_vp), _u64]),
+    "sa_dev_free": (C.c_int, [_vp]),
+    "sa_memcpy_h2d": (C.c_int, [_vp, _vp, _u64]),
+    "sa_memcpy_d2h": (C.c_int, [_vp, _vp, _u64]),
+    "sa_sync": (C.c_int, []),
+    "sa_rfft_peak_f32": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
+    "sa_rfft_peak_f64": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
+    "sa_rfft_peak_f32_dev": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp]),
+    "sa_rfft_peak_f64_dev": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp]),
+    "sa_time_rfft_peak_f32_dev": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _i32,
+                                            C.POINTER(C.c_float)]),
+    "sa_fill_tone_noise_f32_dev": (C.c_int, [_vp, _i64, _i32, _dbl, _u64, _vp]),
+}
+
+
+def load():
+    """Load libspecengine.so (once). Raises OSError with a build hint if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} not found: build it with `make -C fft_amd/csrc` "
+                      "(or python -c 'import __graft_entry__ as g; g.build()'). "
+                      "specengine has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sa_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Map a status code to the exception class the reference's handlers expect."""
+    if rc == SA_OK:
+        return
+    msg = last_error()
+    if rc in (SA_EINVAL, SA_EUNSUP):
+        raise ValueError(msg)
+    if rc == SA_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def ptr(a):
+    """Pointer to a C-contiguous numpy array's data (or None)."""
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+class DeviceBuffer:
+    """A device allocation owned by Python (sa_dev_alloc / sa_dev_free)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = _vp()
+        check(load().sa_dev_alloc(C.byref(p), self.nbytes))
+        self.ptr = p
+
+    def upload(self, arr):
+        assert arr.nbytes <= self.nbytes
+        check(load().sa_memcpy_h2d(self.ptr, ptr(arr), arr.nbytes))
+
+    def download(self, arr, nbytes=None, offset=0):
+        n = arr.nbytes if nbytes is None else nbytes
+        check(load().sa_memcpy_d2h(ptr(arr), _vp(self.ptr.value + offset), n))
+
+    def at(self, offset):
+        return _vp(self.ptr.value + int(offset))
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            load().sa_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,47 @@
+"""Batched window -> rfft -> |Y| (-> dB) -> dominant peak on the GPU (host-array interface).
+
+Replaces, per frame, np.abs(fft(y*w)) + np.argmax of the reference (main.py:475, 479, 1029, 1627)
+with one fused HIP kernel; see include/specengine.h: sa_rfft_peak_f32 / sa_rfft_peak_f64.
+"""
+import numpy as np
+
+from . import _lib
+
+
+def window_id(window):
+    if isinstance(window, (int, np.integer)):
+        return int(window)
+    key = window.lower() if isinstance(window, str) else window
+    if key not in _lib.WINDOW_IDS:
+        raise ValueError(f"unknown window {window!r}")
+    return _lib.WINDOW_IDS[key]
+
+
+def rfft_peak(x, window="hann", win_param=0.0, write_mag=True, db=False, exclude_dc_nyq=False):
+    """x: [batch, n] (or [n]) float32/float64 host array.
+
+    Returns (mag [batch, n/2+1] or None, peak_bin int32[batch], peak_mag [batch]).
+    dtype of x selects the arithmetic (float32 or float64); other dtypes are converted to float64.
+    """
+    x = np.asarray(x)
+    squeeze = x.ndim == 1
+    if squeeze:
+        x = x[None, :]
+    if x.ndim != 2:
+        raise ValueError("x must be [batch, n] or [n]")
+    if x.dtype not in (np.float32, np.float64):
+        x = x.astype(np.float64)
+    x = np.ascontiguousarray(x)
+    batch, n = x.shape
+    flags = (_lib.F_WRITE_MAG if write_mag else 0) | (_lib.F_DB if db else 0) | \
+            (_lib.F_EXCLUDE_DC_NYQ if exclude_dc_nyq else 0)
+    mag = np.empty((batch, n // 2 + 1), dtype=x.dtype) if write_mag else None
+    pb = np.empty(batch, dtype=np.int32)
+    pm = np.empty(batch, dtype=x.dtype)
+    lib = _lib.load()
+    fn = lib.sa_rfft_peak_f32 if x.dtype == np.float32 else lib.sa_rfft_peak_f64
+    _lib.check(fn(_lib.ptr(x), batch, n, window_id(window), float(win_param), flags,
+                  _lib.ptr(mag), _lib.ptr(pb), _lib.ptr(pm)))
+    if squeeze:
+        return (mag[0] if mag is not None else None), pb[0], pm[0]
+    return mag, pb, pm

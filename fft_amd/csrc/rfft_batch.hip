@@ -1,0 +1,283 @@
+// rfft_batch.hip — C ABI + dispatch for the batched window->rfft->|Y|->peak path.
+#include <vector>
+
+#include "rfft_generic.h"
+#include "runtime.h"
+
+namespace sa {
+
+template <typename T, int LOG2M, int P>
+static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
+    constexpr int M = 1 << LOG2M;
+    constexpr int TPF = M / P;
+    constexpr int FPW = TPF >= 256 ? 1 : 256 / TPF;
+    constexpr int S = (sizeof(cplx<T>) == 8) ? 5 : 4;
+    constexpr int LDS_PER_FRAME = lds_pad_c<S>(M) + 1;
+    constexpr int NTHREADS = TPF * FPW;
+    constexpr int NWAVES = (NTHREADS + 63) / 64;
+    constexpr size_t lds = (size_t)FPW * LDS_PER_FRAME * sizeof(cplx<T>) + NWAVES * (sizeof(T) + sizeof(int)) + 16;
+    static_assert(lds <= 160 * 1024, "frame does not fit LDS");
+    auto kern = rfft_mag_peak_generic<T, LOG2M, P, FPW>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t need = (a.batch + FPW - 1) / FPW;
+    const int64_t cap = (int64_t)num_cus() * 8;
+    const int grid = (int)(need < cap ? need : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, a);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+template <typename T>
+static int dispatch_generic(int log2n, const RfftArgs<T>& a, hipStream_t st);
+
+template <>
+int dispatch_generic<float>(int log2n, const RfftArgs<float>& a, hipStream_t st) {
+    switch (log2n) {
+        case 4: return launch_generic<float, 3, 8>(a, st);
+        case 5: return launch_generic<float, 4, 8>(a, st);
+        case 6: return launch_generic<float, 5, 8>(a, st);
+        case 7: return launch_generic<float, 6, 8>(a, st);
+        case 8: return launch_generic<float, 7, 8>(a, st);
+        case 9: return launch_generic<float, 8, 8>(a, st);
+        case 10: return launch_generic<float, 9, 8>(a, st);
+        case 11: return launch_generic<float, 10, 8>(a, st);
+        case 12: return launch_generic<float, 11, 8>(a, st);
+        case 13: return launch_generic<float, 12, 8>(a, st);
+        case 14: return launch_generic<float, 13, 8>(a, st);
+        case 15: return launch_generic<float, 14, 16>(a, st);
+    }
+    set_error("rfft f32: n=2^%d unsupported (16 <= n <= 32768, power of two)", log2n);
+    return SA_EUNSUP;
+}
+
+template <>
+int dispatch_generic<double>(int log2n, const RfftArgs<double>& a, hipStream_t st) {
+    switch (log2n) {
+        case 4: return launch_generic<double, 3, 8>(a, st);
+        case 5: return launch_generic<double, 4, 8>(a, st);
+        case 6: return launch_generic<double, 5, 8>(a, st);
+        case 7: return launch_generic<double, 6, 8>(a, st);
+        case 8: return launch_generic<double, 7, 8>(a, st);
+        case 9: return launch_generic<double, 8, 8>(a, st);
+        case 10: return launch_generic<double, 9, 8>(a, st);
+        case 11: return launch_generic<double, 10, 8>(a, st);
+        case 12: return launch_generic<double, 11, 8>(a, st);
+        case 13: return launch_generic<double, 12, 8>(a, st);
+        case 14: return launch_generic<double, 13, 8>(a, st);
+    }
+    set_error("rfft f64: n=2^%d unsupported (16 <= n <= 16384, power of two)", log2n);
+    return SA_EUNSUP;
+}
+
+static int ilog2_exact(int64_t n) {
+    if (n <= 0 || (n & (n - 1))) return -1;
+    int l = 0;
+    while ((1LL << l) < n) ++l;
+    return l;
+}
+
+template <typename T>
+static int check_args(const T* x, int64_t batch, int32_t n, int32_t window, int32_t flags, T* mag,
+                      int32_t* peak_bin, T* peak_mag, int* log2n) {
+    if (batch < 0) { set_error("batch must be >= 0 (got %lld)", (long long)batch); return SA_EINVAL; }
+    if (window < SA_WIN_NONE || window > SA_WIN_GAUSSIAN) { set_error("unknown window id %d", window); return SA_EINVAL; }
+    *log2n = ilog2_exact(n);
+    if (*log2n < 0) { set_error("n=%d is not a power of two; use sa_fft_mag_f64 for arbitrary n", n); return SA_EUNSUP; }
+    if (n < 16) { set_error("n=%d < 16 (reference rejects N < 16, main.py:512)", n); return SA_EINVAL; }
+    if (batch > 0 && (!x || !peak_bin || !peak_mag)) { set_error("x, peak_bin and peak_mag must be non-NULL"); return SA_EINVAL; }
+    if ((flags & SA_F_WRITE_MAG) && !mag && batch > 0) { set_error("SA_F_WRITE_MAG set but mag is NULL"); return SA_EINVAL; }
+    if (flags & ~7) { set_error("unknown flag bits 0x%x", flags & ~7); return SA_EINVAL; }
+    return SA_OK;
+}
+
+template <typename T>
+int rfft_peak_dev(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
+                  T* mag, int32_t* peak_bin, T* peak_mag, hipStream_t st) {
+    SA_TRY(ensure_init());
+    int log2n = 0;
+    SA_TRY(check_args(x, batch, n, window, flags, mag, peak_bin, peak_mag, &log2n));
+    if (batch == 0) return SA_OK;
+    const RfftPlan* p = get_rfft_plan(sizeof(T) == 8, n, window, win_param);
+    if (!p) return SA_EHIP;
+    RfftArgs<T> a;
+    a.x = x; a.batch = batch;
+    a.win = static_cast<const T*>(p->d_win);
+    a.twM = static_cast<const cplx<T>*>(p->d_twM);
+    a.twN = static_cast<const cplx<T>*>(p->d_twN);
+    a.flags = flags; a.mag = mag; a.peak_bin = peak_bin; a.peak_mag = peak_mag;
+    a.db_floor = sizeof(T) == 8 ? (T)SA_DB_FLOOR_F64 : (T)SA_DB_FLOOR_F32;
+    return dispatch_generic<T>(log2n, a, st);
+}
+
+// Host-pointer variant: stage through device memory in chunks, synchronise before returning.
+template <typename T>
+int rfft_peak_host(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
+                   T* mag, int32_t* peak_bin, T* peak_mag) {
+    SA_TRY(ensure_init());
+    int log2n = 0;
+    SA_TRY(check_args(x, batch, n, window, flags, mag, peak_bin, peak_mag, &log2n));
+    if (batch == 0) return SA_OK;
+    hipStream_t st = thread_stream();
+    const bool wmag = (flags & SA_F_WRITE_MAG) != 0;
+    const int64_t nb = n / 2 + 1;
+    // chunk so that the staging buffers stay <= ~1 GiB
+    int64_t chunk = (int64_t)(1ull << 30) / ((int64_t)n * sizeof(T));
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    T *dx = nullptr, *dmag = nullptr, *dpm = nullptr;
+    int32_t* dpb = nullptr;
+    int rc = SA_OK;
+    auto cleanup = [&]() {
+        if (dx) hipFree(dx);
+        if (dmag) hipFree(dmag);
+        if (dpm) hipFree(dpm);
+        if (dpb) hipFree(dpb);
+    };
+#define SA_HIP_C(call)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_error("%s failed: %s", #call, hipGetErrorString(e_));                         \
+            cleanup();                                                                        \
+            return (e_ == hipErrorOutOfMemory) ? SA_ENOMEM : SA_EHIP;                         \
+        }                                                                                     \
+    } while (0)
+    SA_HIP_C(hipMalloc(&dx, chunk * n * sizeof(T)));
+    if (wmag) SA_HIP_C(hipMalloc(&dmag, chunk * nb * sizeof(T)));
+    SA_HIP_C(hipMalloc(&dpm, chunk * sizeof(T)));
+    SA_HIP_C(hipMalloc(&dpb, chunk * sizeof(int32_t)));
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nbt = (batch - b0 < chunk) ? batch - b0 : chunk;
+        SA_HIP_C(hipMemcpyAsync(dx, x + b0 * n, nbt * n * sizeof(T), hipMemcpyHostToDevice, st));
+        rc = rfft_peak_dev<T>(dx, nbt, n, window, win_param, flags, dmag, dpb, dpm, st);
+        if (rc != SA_OK) { cleanup(); return rc; }
+        if (wmag) SA_HIP_C(hipMemcpyAsync(mag + b0 * nb, dmag, nbt * nb * sizeof(T), hipMemcpyDeviceToHost, st));
+        SA_HIP_C(hipMemcpyAsync(peak_bin + b0, dpb, nbt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        SA_HIP_C(hipMemcpyAsync(peak_mag + b0, dpm, nbt * sizeof(T), hipMemcpyDeviceToHost, st));
+        SA_HIP_C(hipStreamSynchronize(st));
+    }
+#undef SA_HIP_C
+    cleanup();
+    return SA_OK;
+}
+
+// ---- synthetic C2 frames: Philox4x32-10 keyed by seed, counter = (frame, sample group) ---------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ void fill_tone_noise_kernel(float* x, int64_t batch, int n, double fs, uint32_t k0, uint32_t k1) {
+    const int64_t total4 = batch * (int64_t)(n / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / (n / 4);
+        const int s4 = (int)(i % (n / 4));
+        uint32_t r[4], q[4];
+        // per-frame parameters: counter (b, 0xFFFFFFFF)
+        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), 0xFFFFFFFFu, 0u, k0, k1, q);
+        double pbin = (1000.0 + 48000.0 * (double)u01(q[0])) * n / fs;   // tone position in bins
+        const double fr = pbin - floor(pbin);
+        if (fr > 0.48 && fr < 0.52) pbin += 0.05;                        // keep away from half-bin ties
+        const float amp = 0.5f + 0.5f * u01(q[1]);
+        const double phi = 6.283185307179586 * (double)u01(q[2]);
+        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)s4, 1u, k0, k1, r);
+        float g[4];
+        {
+            const float r0 = sqrtf(-2.0f * logf(u01(r[0]))), r1 = sqrtf(-2.0f * logf(u01(r[2])));
+            float s, c;
+            sincosf(6.2831853f * u01(r[1]), &s, &c); g[0] = r0 * c; g[1] = r0 * s;
+            sincosf(6.2831853f * u01(r[3]), &s, &c); g[2] = r1 * c; g[3] = r1 * s;
+        }
+        float4 o;
+        float* op = &o.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int nn = s4 * 4 + e;
+            double turns = pbin * (double)nn / (double)n;        // cycles
+            turns -= floor(turns);
+            op[e] = amp * (float)sin(6.283185307179586 * turns + phi) + 0.01f * g[e];
+        }
+        reinterpret_cast<float4*>(x)[i] = o;
+    }
+}
+
+}  // namespace sa
+
+extern "C" {
+
+int sa_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
+                         float* mag, int32_t* peak_bin, float* peak_mag, void* stream) {
+    SA_TRY(sa::ensure_init());
+    hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
+    return sa::rfft_peak_dev<float>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
+}
+int sa_rfft_peak_f64_dev(const double* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
+                         double* mag, int32_t* peak_bin, double* peak_mag, void* stream) {
+    SA_TRY(sa::ensure_init());
+    hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
+    return sa::rfft_peak_dev<double>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
+}
+int sa_rfft_peak_f32(const float* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
+                     float* mag, int32_t* peak_bin, float* peak_mag) {
+    return sa::rfft_peak_host<float>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag);
+}
+int sa_rfft_peak_f64(const double* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
+                     double* mag, int32_t* peak_bin, double* peak_mag) {
+    return sa::rfft_peak_host<double>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag);
+}
+
+int sa_time_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param,
+                              int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, int32_t iters,
+                              float* ms_avg) {
+    SA_TRY(sa::ensure_init());
+    if (iters <= 0 || !ms_avg) { sa::set_error("iters must be > 0 and ms_avg non-NULL"); return SA_EINVAL; }
+    hipStream_t st = sa::thread_stream();
+    hipEvent_t e0, e1;
+    SA_HIP(hipEventCreate(&e0));
+    SA_HIP(hipEventCreate(&e1));
+    // one untimed launch builds the plan
+    int rc = sa::rfft_peak_dev<float>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
+    if (rc == SA_OK) {
+        hipEventRecord(e0, st);
+        for (int i = 0; i < iters && rc == SA_OK; ++i)
+            rc = sa::rfft_peak_dev<float>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
+        hipEventRecord(e1, st);
+        hipError_t e = hipEventSynchronize(e1);
+        if (rc == SA_OK && e != hipSuccess) { sa::set_error("hipEventSynchronize: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+        float ms = 0;
+        if (rc == SA_OK) { hipEventElapsedTime(&ms, e0, e1); *ms_avg = ms / iters; }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+}
+
+int sa_fill_tone_noise_f32_dev(float* x, int64_t batch, int32_t n, double fs, uint64_t seed, void* stream) {
+    SA_TRY(sa::ensure_init());
+    if (!x || batch < 0 || n < 4 || (n & 3)) { sa::set_error("sa_fill_tone_noise_f32_dev: bad arguments"); return SA_EINVAL; }
+    if (batch == 0) return SA_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
+    hipLaunchKernelGGL(sa::fill_tone_noise_kernel, dim3(sa::num_cus() * 8), dim3(256), 0, st, x, batch, n, fs,
+                       (uint32_t)seed, (uint32_t)(seed >> 32));
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+}  // extern "C"

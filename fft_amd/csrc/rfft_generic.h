@@ -1,0 +1,221 @@
+// rfft_generic.h — generic fused  window -> real FFT -> |Y| (-> dB) -> argmax  kernel for any
+// power-of-two frame length that fits one workgroup's LDS (n = 16 .. 32768 f32 / 16384 f64).
+//
+// Replaces per frame:  np.abs(fft(y*w)) and np.argmax  (reference main.py:475, 479, 1029, 1627).
+//
+// Algorithm: the n real samples are packed as M = n/2 complex points z[j] = x[2j] + i x[2j+1];
+// an M-point decimation-in-frequency FFT runs with the data held in registers (P points per
+// thread) and one LDS exchange between radix passes; a Hermitian post-pass turns Z into the
+// n/2+1 real-FFT bins, takes magnitudes, stores them coalesced and reduces the dominant peak.
+// One HBM read of the frame, one HBM write of the spectrum; twiddles / window come from small
+// L2-resident tables (the tuned n=4096 kernel in rfft4096.h keeps them in registers instead).
+#pragma once
+#include "fft_core.h"
+
+namespace sa {
+
+// ---- compile-time pass plan: radix-8 passes, then one 4 or 2 ---------------------------------
+template <int LOG2M> struct Plan {
+    static constexpr int M = 1 << LOG2M;
+    static constexpr int N8 = LOG2M / 3;
+    static constexpr int REM = LOG2M % 3;            // 0,1,2 -> extra radix 1,2,4
+    static constexpr int NP = N8 + (REM ? 1 : 0);
+    static constexpr int radix(int j) { return j < N8 ? 8 : (1 << REM); }
+    // H_{j} = R_1...R_j (product of the first j radices), M_j = M / H_j
+    static constexpr int H(int j) { int h = 1; for (int i = 0; i < j; ++i) h *= radix(i); return h; }
+};
+
+struct PeakCand { double mag; int bin; };   // only used on the host side
+
+template <typename T> __device__ __forceinline__ bool peak_better(T m, int k, T bm, int bk) {
+    return (m > bm) || (m == bm && k < bk);
+}
+
+// Kernel parameters
+template <typename T> struct RfftArgs {
+    const T* x;            // [batch][n]
+    int64_t batch;
+    const T* win;          // [n] or nullptr (SA_WIN_NONE)
+    const cplx<T>* twM;    // [M]      w_M^i
+    const cplx<T>* twN;    // [M/2+1]  w_N^i
+    int flags;
+    T* mag;                // [batch][M+1] or nullptr
+    int32_t* peak_bin;     // [batch]
+    T* peak_mag;           // [batch]
+    T db_floor;
+};
+
+template <typename T, int LOG2M, int P /*points per thread*/, int FPW /*frames per workgroup*/>
+__global__ void __launch_bounds__((((1 << LOG2M) / P) * FPW))
+rfft_mag_peak_generic(RfftArgs<T> a) {
+    using C = cplx<T>;
+    using PL = Plan<LOG2M>;
+    constexpr int M = 1 << LOG2M;
+    constexpr int TPF = M / P;                       // threads per frame
+    constexpr int S = (sizeof(C) == 8) ? 5 : 4;      // pad granule (elements per LDS bank row)
+    constexpr int LDS_PER_FRAME = lds_pad_c<S>(M) + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    C* smem = reinterpret_cast<C*>(smem_raw);
+
+    const int g = threadIdx.x / TPF;                 // frame slot inside the workgroup
+    const int tl = threadIdx.x % TPF;
+    C* buf = smem + g * LDS_PER_FRAME;
+    // peak scratch after the frame buffers: per wave candidates
+    constexpr int NTHREADS = TPF * FPW;
+    constexpr int NWAVES = (NTHREADS + 63) / 64;
+    T* red_mag = reinterpret_cast<T*>(smem + FPW * LDS_PER_FRAME);
+    int* red_bin = reinterpret_cast<int*>(red_mag + NWAVES);
+
+    for (int64_t base = (int64_t)blockIdx.x * FPW; base < a.batch; base += (int64_t)gridDim.x * FPW) {
+        const int64_t frame = base + g;
+        const bool valid = frame < a.batch;
+        const T* xf = a.x + (valid ? frame : 0) * (int64_t)(2 * M);
+        C v[P];
+
+        // ---------------- pass 0: global load (+window) -> butterfly -> LDS ----------------
+        {
+            constexpr int R = PL::radix(0);
+            constexpr int Mj = M / R;                // tail length after this pass
+#pragma unroll
+            for (int u = 0; u < P / R; ++u) {
+                const int id = tl + TPF * u;         // = m' (h = 0)
+#pragma unroll
+                for (int n1 = 0; n1 < R; ++n1) {
+                    const int c = n1 * Mj + id;
+                    C z = valid ? *reinterpret_cast<const C*>(xf + 2 * c) : mk<T>(0, 0);
+                    if (a.win) {
+                        const C w = *reinterpret_cast<const C*>(a.win + 2 * c);
+                        z.x *= w.x; z.y *= w.y;
+                    }
+                    v[u * R + n1] = z;
+                }
+                bfly<T, R>(&v[u * R]);
+                if constexpr (PL::NP > 1) {
+#pragma unroll
+                    for (int k = 1; k < R; ++k) v[u * R + k] = cmul(v[u * R + k], a.twM[id * k]);
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) buf[lds_pad<S>(k * Mj + id)] = v[u * R + k];
+            }
+        }
+        // ---------------- passes 1 .. NP-1 --------------------------------------------------
+#pragma unroll
+        for (int j = 1; j < PL::NP; ++j) {
+            const int R = PL::radix(j);              // constant after unrolling
+            const int Hprev = PL::H(j);              // R_1..R_{j}   (heads so far)
+            const int Mprev = M / Hprev;             // tail length before this pass
+            const int Mj = Mprev / R;                // tail length after this pass
+            __syncthreads();
+            if (R == 8) {
+#pragma unroll
+                for (int u = 0; u < P / 8; ++u) {
+                    const int id = tl + TPF * u;
+                    const int mp = id % Mj, h = id / Mj;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) v[u * 8 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
+                    bfly<T, 8>(&v[u * 8]);
+                    if (Mj > 1) {
+#pragma unroll
+                        for (int k = 1; k < 8; ++k) v[u * 8 + k] = cmul(v[u * 8 + k], a.twM[Hprev * mp * k]);
+                    }
+                }
+            } else if (R == 4) {
+#pragma unroll
+                for (int u = 0; u < P / 4; ++u) {
+                    const int id = tl + TPF * u;
+                    const int mp = id % Mj, h = id / Mj;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) v[u * 4 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
+                    bfly<T, 4>(&v[u * 4]);
+                    if (Mj > 1) {
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) v[u * 4 + k] = cmul(v[u * 4 + k], a.twM[Hprev * mp * k]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < P / 2; ++u) {
+                    const int id = tl + TPF * u;
+                    const int mp = id % Mj, h = id / Mj;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) v[u * 2 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
+                    bfly<T, 2>(&v[u * 2]);
+                    if (Mj > 1) v[u * 2 + 1] = cmul(v[u * 2 + 1], a.twM[Hprev * mp]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < P / R; ++u) {
+                const int id = tl + TPF * u;
+                const int mp = id % Mj, h = id / Mj;
+#pragma unroll
+                for (int k = 0; k < R; ++k) buf[lds_pad<S>((h + Hprev * k) * Mj + mp)] = v[u * R + k];
+            }
+        }
+        __syncthreads();
+
+        // ---------------- Hermitian post-pass: Z -> X[0..M], |X|, peak ----------------------
+        T best = (T)-1;
+        int best_k = 0x7fffffff;
+        const bool excl = (a.flags & 4) != 0;
+        const bool wmag = (a.flags & 1) != 0 && a.mag != nullptr;
+        const bool wdb = (a.flags & 2) != 0;
+        T* mf = wmag ? a.mag + (valid ? frame : 0) * (int64_t)(M + 1) : nullptr;
+        constexpr int NPAIR = M / 2 + 1;             // q = 0 .. M/2
+#pragma unroll
+        for (int u = 0; u < (NPAIR + TPF - 1) / TPF; ++u) {
+            const int q = tl + TPF * u;
+            if (q < NPAIR) {
+                const C zq = buf[lds_pad<S>(q)];
+                const C zm = buf[lds_pad<S>((M - q) & (M - 1))];
+                // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
+                const C e = mk<T>((T)0.5 * (zq.x + zm.x), (T)0.5 * (zq.y - zm.y));
+                const C d = mk<T>((T)0.5 * (zq.x - zm.x), (T)0.5 * (zq.y + zm.y));
+                const C o = mk<T>(d.y, -d.x);
+                const C wo = cmul(o, a.twN[q]);
+                const C xa = cadd(e, wo);            // X[q]
+                const C xb = csub(e, wo);            // conj(X[M-q])
+                const T ma = sqrt(xa.x * xa.x + xa.y * xa.y);
+                const T mb = sqrt(xb.x * xb.x + xb.y * xb.y);
+                const int ka = q, kb = M - q;
+                if (wmag && valid) {
+                    mf[ka] = wdb ? (T)20 * log10(fmax(ma, a.db_floor)) : ma;
+                    if (kb != ka) mf[kb] = wdb ? (T)20 * log10(fmax(mb, a.db_floor)) : mb;
+                }
+                const bool oka = !(excl && ka == 0);
+                const bool okb = !(excl && kb == M) && kb != ka;
+                if (oka && peak_better(ma, ka, best, best_k)) { best = ma; best_k = ka; }
+                if (okb && peak_better(mb, kb, best, best_k)) { best = mb; best_k = kb; }
+            }
+        }
+        // reduce (best, best_k) over the TPF threads of this frame
+        constexpr int WREDUCE = TPF < 64 ? TPF : 64;
+#pragma unroll
+        for (int off = WREDUCE / 2; off > 0; off >>= 1) {
+            const T om = __shfl_xor(best, off);
+            const int ok = __shfl_xor(best_k, off);
+            if (peak_better(om, ok, best, best_k)) { best = om; best_k = ok; }
+        }
+        if constexpr (TPF > 64) {
+            const int wave = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) { red_mag[wave] = best; red_bin[wave] = best_k; }
+            __syncthreads();
+            if (tl == 0) {
+                constexpr int WPF = TPF / 64;
+                const int w0 = g * WPF;
+                for (int w = 1; w < WPF; ++w) {
+                    const T om = red_mag[w0 + w];
+                    const int ok = red_bin[w0 + w];
+                    if (peak_better(om, ok, best, best_k)) { best = om; best_k = ok; }
+                }
+            }
+        }
+        if (tl == 0 && valid) {
+            a.peak_bin[frame] = best_k;
+            a.peak_mag[frame] = best;
+        }
+        __syncthreads();   // buf and red_* are reused by the next frame
+    }
+}
+
+}  // namespace sa

@@ -1,0 +1,58 @@
+// runtime.h — host-side runtime shared by the translation units of libspecengine.so:
+// error reporting, lazy device init, per-thread streams, and the plan cache (device-resident
+// window / twiddle tables keyed by (dtype, n, window, win_param)).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/specengine.h"
+
+namespace sa {
+
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+int ensure_init();                 // SA_OK or error (message set)
+hipStream_t thread_stream();       // the calling thread's library stream on the current device
+int num_cus();                     // multiprocessor count of the current device
+
+#define SA_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ::sa::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                            __LINE__);                                                       \
+            return (e_ == hipErrorOutOfMemory) ? SA_ENOMEM : SA_EHIP;                        \
+        }                                                                                    \
+    } while (0)
+
+#define SA_TRY(expr)                 \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != SA_OK) return rc_; \
+    } while (0)
+
+// Host-side table builders (double precision, exact octant reduction for twiddles).
+void host_window(int window, double win_param, int n, std::vector<double>& w);
+void host_twiddle(int64_t n, int64_t count, int64_t stride, std::vector<double>& re_im);  // w_n^{stride*i}, i<count
+
+// A device-resident table set for the batched rfft kernels.
+struct RfftPlan {
+    int n = 0;
+    bool f64 = false;
+    int window = 0;
+    double win_param = 0;
+    void* d_win = nullptr;   // T[n] or nullptr
+    void* d_twM = nullptr;   // cplx<T>[n/2]
+    void* d_twN = nullptr;   // cplx<T>[n/4+1]
+};
+// Returns a cached plan (creates it on first use; thread safe). nullptr + error on failure.
+const RfftPlan* get_rfft_plan(bool f64, int n, int window, double win_param);
+
+// Generic cached device buffer of doubles/floats uploaded from a host vector, keyed by a string.
+// Used by the c2c / Bluestein / STFT paths for their tables.
+const void* get_cached_table(const std::string& key, size_t bytes, void (*fill)(void* host, void* ctx), void* ctx);
+
+void free_all_plans();
+
+}  // namespace sa

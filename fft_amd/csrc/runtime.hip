@@ -1,0 +1,279 @@
+// runtime.hip — lazy init, errors, streams, device memory helpers and the plan cache.
+#include "runtime.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+namespace sa {
+
+static thread_local char g_err[512] = "";
+static std::mutex g_mu;
+static bool g_inited = false;
+static int g_ncus = 256;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int num_cus() { return g_ncus; }
+
+int ensure_init() {
+    if (g_inited) return SA_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_inited) return SA_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); specengine has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return SA_ENODEV;
+    }
+    int dev = 0;
+    SA_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    SA_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+        return SA_ENODEV;
+    }
+    g_ncus = prop.multiProcessorCount;
+    g_inited = true;
+    return SA_OK;
+}
+
+// one stream per (host thread, device)
+struct ThreadStreams {
+    std::map<int, hipStream_t> s;
+    ~ThreadStreams() {
+        // Streams are intentionally not destroyed at thread exit: the HIP runtime may already be
+        // shutting down when thread_local destructors run.
+    }
+};
+static thread_local ThreadStreams g_streams;
+
+hipStream_t thread_stream() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    auto it = g_streams.s.find(dev);
+    if (it != g_streams.s.end()) return it->second;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    g_streams.s[dev] = st;
+    return st;
+}
+
+// ---- host table builders ------------------------------------------------------------------------
+// np.hanning / np.hamming / np.blackman (numpy/lib/_function_base_impl.py) and
+// scipy.signal.windows.gaussian(M, std, sym=True): all symmetric, n in [0, N-1], denominator N-1.
+void host_window(int window, double win_param, int n, std::vector<double>& w) {
+    w.assign(n, 1.0);
+    if (window == SA_WIN_NONE) return;
+    if (n == 1) { w[0] = 1.0; return; }
+    const double pi = 3.14159265358979323846264338327950288;
+    if (window == SA_WIN_GAUSSIAN) {
+        const double std_ = win_param > 0 ? win_param : (n - 1) / 5.0;
+        for (int i = 0; i < n; ++i) {
+            const double x = i - (n - 1) / 2.0;
+            w[i] = exp(-0.5 * (x / std_) * (x / std_));
+        }
+        return;
+    }
+    for (int i = 0; i < n; ++i) {
+        // numpy evaluates cos(pi * k / (N-1)) with k = 1-N, 3-N, ..., N-1  (k = 2 i - (N-1))
+        const double k = 2.0 * i - (n - 1);
+        const double a = pi * k / (n - 1);
+        if (window == SA_WIN_HANN) w[i] = 0.5 + 0.5 * cos(a);
+        else if (window == SA_WIN_HAMMING) w[i] = 0.54 + 0.46 * cos(a);
+        else if (window == SA_WIN_BLACKMAN) w[i] = 0.42 + 0.5 * cos(a) + 0.08 * cos(2.0 * a);
+    }
+}
+
+// exp(-2 pi i * num / den) with exact octant reduction (long double kernel on a reduced argument)
+static void exact_twiddle(int64_t num, int64_t den, double* re, double* im) {
+    num %= den;
+    if (num < 0) num += den;
+    // angle = 2 pi num/den in [0, 2pi). Reduce to octant: 8*num/den = o + f
+    const __int128 n8 = (__int128)num * 8;
+    int64_t oct = (int64_t)(n8 / den);
+    int64_t rem = (int64_t)(n8 % den);          // fraction rem/den of an octant (pi/4)
+    const long double pil = 3.14159265358979323846264338327950288L;
+    long double c, s;
+    // use the smaller of rem and den-rem to stay near 0
+    auto cs = [&](int64_t r, long double* cc, long double* ss) {
+        const long double ang = pil / 4 * ((long double)r / (long double)den);
+        *cc = cosl(ang); *ss = sinl(ang);
+    };
+    if (oct & 1) {           // odd octant: angle = (oct+1) pi/4 - (den-rem)/den pi/4
+        long double c2, s2;
+        cs(den - rem, &c2, &s2);
+        // cos((oct+1)pi/4 - b), sin(...) with (oct+1)/2 quarter turns
+        const int q = (int)((oct + 1) / 2) & 3;
+        // cos(q pi/2 - b), sin(q pi/2 - b)
+        switch (q) {
+            case 0: c = c2; s = -s2; break;
+            case 1: c = s2; s = c2; break;
+            case 2: c = -c2; s = s2; break;
+            default: c = -s2; s = -c2; break;
+        }
+    } else {
+        long double c2, s2;
+        cs(rem, &c2, &s2);
+        const int q = (int)(oct / 2) & 3;   // angle = q pi/2 + b
+        switch (q) {
+            case 0: c = c2; s = s2; break;
+            case 1: c = -s2; s = c2; break;
+            case 2: c = -c2; s = -s2; break;
+            default: c = s2; s = -c2; break;
+        }
+    }
+    *re = (double)c;
+    *im = (double)(-s);
+}
+
+void host_twiddle(int64_t n, int64_t count, int64_t stride, std::vector<double>& re_im) {
+    re_im.resize(2 * count);
+    for (int64_t i = 0; i < count; ++i) exact_twiddle(i * stride, n, &re_im[2 * i], &re_im[2 * i + 1]);
+}
+
+// ---- plan cache ---------------------------------------------------------------------------------
+using PlanKey = std::tuple<int /*dev*/, bool, int, int, double>;
+static std::map<PlanKey, RfftPlan*> g_plans;
+static std::map<std::string, void*> g_tables;
+
+template <typename T>
+static int upload(const std::vector<double>& src, void** dptr) {
+    std::vector<T> tmp(src.begin(), src.end());
+    SA_HIP(hipMalloc(dptr, tmp.size() * sizeof(T)));
+    SA_HIP(hipMemcpy(*dptr, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SA_OK;
+}
+
+const RfftPlan* get_rfft_plan(bool f64, int n, int window, double win_param) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (window != SA_WIN_GAUSSIAN) win_param = 0;
+    PlanKey key(dev, f64, n, window, win_param);
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    RfftPlan* p = new RfftPlan;
+    p->n = n; p->f64 = f64; p->window = window; p->win_param = win_param;
+    std::vector<double> w, twM, twN;
+    const int M = n / 2;
+    host_twiddle(M, M, 1, twM);
+    host_twiddle(n, M / 2 + 1, 1, twN);
+    int rc = SA_OK;
+    if (window != SA_WIN_NONE) {
+        host_window(window, win_param, n, w);
+        rc = f64 ? upload<double>(w, &p->d_win) : upload<float>(w, &p->d_win);
+    }
+    if (rc == SA_OK) rc = f64 ? upload<double>(twM, &p->d_twM) : upload<float>(twM, &p->d_twM);
+    if (rc == SA_OK) rc = f64 ? upload<double>(twN, &p->d_twN) : upload<float>(twN, &p->d_twN);
+    if (rc != SA_OK) {
+        if (p->d_win) hipFree(p->d_win);
+        if (p->d_twM) hipFree(p->d_twM);
+        if (p->d_twN) hipFree(p->d_twN);
+        delete p;
+        return nullptr;
+    }
+    g_plans[key] = p;
+    return p;
+}
+
+const void* get_cached_table(const std::string& key0, size_t bytes, void (*fill)(void*, void*), void* ctx) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    const std::string key = std::to_string(dev) + ":" + key0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) return it->second;
+    std::vector<char> host(bytes);
+    fill(host.data(), ctx);
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) { set_error("hipMalloc(%zu) failed for table %s", bytes, key0.c_str()); return nullptr; }
+    if (hipMemcpy(d, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("hipMemcpy failed for table %s", key0.c_str());
+        hipFree(d);
+        return nullptr;
+    }
+    g_tables[key] = d;
+    return d;
+}
+
+void free_all_plans() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_plans) {
+        RfftPlan* p = kv.second;
+        if (p->d_win) hipFree(p->d_win);
+        if (p->d_twM) hipFree(p->d_twM);
+        if (p->d_twN) hipFree(p->d_twN);
+        delete p;
+    }
+    g_plans.clear();
+    for (auto& kv : g_tables) hipFree(kv.second);
+    g_tables.clear();
+}
+
+}  // namespace sa
+
+// ---- C ABI: runtime -----------------------------------------------------------------------------
+extern "C" {
+
+const char* sa_last_error(void) { return sa::g_err; }
+const char* sa_version(void) { return "specengine 0.1 (gfx950)"; }
+
+int sa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sa_set_device(int device) {
+    SA_HIP(hipSetDevice(device));
+    return SA_OK;
+}
+
+int sa_init(int device) {
+    if (device >= 0) SA_HIP(hipSetDevice(device));
+    return sa::ensure_init();
+}
+
+void sa_shutdown(void) {
+    hipDeviceSynchronize();
+    sa::free_all_plans();
+}
+
+int sa_dev_alloc(void** dptr, uint64_t bytes) {
+    SA_TRY(sa::ensure_init());
+    if (!dptr) { sa::set_error("sa_dev_alloc: dptr is NULL"); return SA_EINVAL; }
+    SA_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return SA_OK;
+}
+int sa_dev_free(void* dptr) {
+    if (dptr) SA_HIP(hipFree(dptr));
+    return SA_OK;
+}
+int sa_memcpy_h2d(void* dst, const void* src, uint64_t bytes) {
+    SA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return SA_OK;
+}
+int sa_memcpy_d2h(void* dst, const void* src, uint64_t bytes) {
+    SA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return SA_OK;
+}
+int sa_sync(void) {
+    SA_TRY(sa::ensure_init());
+    SA_HIP(hipStreamSynchronize(sa::thread_stream()));
+    return SA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+/*
+ * specengine.h — C ABI of the MI355X (gfx950) spectrum-analysis hot path.
+ *
+ * This is the drop-in boundary for the numeric core of the Gecesars/FFT analyzer
+ *     t = arange(N)/Fs -> _generate_waveform -> _apply_modulation -> fftshift(fft(y)) -> abs -> argmax
+ * (reference: main.py:452-479, 536-629, 959-965, 1029, 1318, 1622-1629; versão15.py:425-461, 590-602, 814).
+ * The reference has no FFI of its own (pure numpy/scipy methods on a GUI class), so each entry point
+ * cites the reference lines whose arithmetic it replaces.  The Python mirror of the reference
+ * interface (calculate_fft / compute / dominant_peak) lives in fft_amd/specengine.py and binds
+ * exactly these symbols through ctypes; INTEGRATION.md shows the 3-line patch to main.py.
+ *
+ * Conventions
+ *   - plain C, caller owns every buffer, the library never returns memory it allocated
+ *     (except through sa_dev_alloc, which the caller frees with sa_dev_free);
+ *   - every function returns 0 (SA_OK) or a negative SA_E* code; the message is in sa_last_error()
+ *     (thread local);
+ *   - "host" entry points take host pointers, stage through device memory and synchronise before
+ *     returning; "*_dev" entry points take device pointers, enqueue on `stream` (a hipStream_t cast
+ *     to void*, NULL = the library's per-thread stream) and do NOT synchronise;
+ *   - thread safe: may be called concurrently from several host threads (the reference calls the
+ *     path from a ThreadPoolExecutor worker and from the Tk main thread, main.py:448, 745, 1080);
+ *   - there is no CPU fallback: without a gfx950 device every compute entry point fails with SA_ENODEV.
+ */
+#ifndef SPECENGINE_H
+#define SPECENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define SA_OK        0
+#define SA_EINVAL   -1   /* bad argument (shim raises ValueError, as main.py:531 catches)          */
+#define SA_ENODEV   -2   /* no usable HIP device                                                   */
+#define SA_EHIP     -3   /* HIP runtime error (shim raises RuntimeError -> main.py:485 handler)    */
+#define SA_ENOMEM   -4   /* device or host allocation failed                                       */
+#define SA_EUNSUP   -5   /* size / option not supported by this build                              */
+
+/* ---- window ids (a11: README.md:13 claim; formulas = numpy/scipy symmetric windows, which agree
+ *      with the firmware's apply_window, Core/Src/main.c:83-99) -------------------------------- */
+#define SA_WIN_NONE      0
+#define SA_WIN_HANN      1   /* np.hanning(N)   = 0.5 - 0.5 cos(2 pi n/(N-1))                       */
+#define SA_WIN_HAMMING   2   /* np.hamming(N)   = 0.54 - 0.46 cos(2 pi n/(N-1))                     */
+#define SA_WIN_BLACKMAN  3   /* np.blackman(N)  = 0.42 - 0.5 cos(2 pi n/(N-1)) + 0.08 cos(4 pi n/(N-1)) */
+#define SA_WIN_GAUSSIAN  4   /* scipy.signal.windows.gaussian(N, std=win_param, sym=True);
+                                win_param <= 0 selects std = (N-1)/5                                */
+
+/* ---- flags -------------------------------------------------------------------------------- */
+#define SA_F_WRITE_MAG       1   /* write the N/2+1 magnitudes per frame (else peak only)          */
+#define SA_F_DB              2   /* magnitudes written as 20*log10(max(|Y|, SA_DB_FLOOR)) dB        */
+#define SA_F_EXCLUDE_DC_NYQ  4   /* peak search over bins 1..N/2-1 only (mirrors the f>0 mask of
+                                    main.py:1622-1627, which drops DC and, for even N, Nyquist)     */
+#define SA_DB_FLOOR_F32 1e-30f
+#define SA_DB_FLOOR_F64 1e-300
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+/* Initialise the library on the calling process' current HIP device (or `device` >= 0).
+ * Idempotent; every other entry point calls it lazily.  Replaces nothing in the reference
+ * (which is host-only) — it is the device boundary inserted at main.py:460-479. */
+int  sa_init(int device /* -1 = keep current */);
+void sa_shutdown(void);
+int  sa_device_count(void);
+int  sa_set_device(int device);
+const char* sa_last_error(void);
+const char* sa_version(void);
+
+/* Device memory + copies for callers that keep data resident (bench, multi-GPU shards). */
+int  sa_dev_alloc(void** dptr, uint64_t bytes);
+int  sa_dev_free(void* dptr);
+int  sa_memcpy_h2d(void* dst_dev, const void* src_host, uint64_t bytes);
+int  sa_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes);
+int  sa_sync(void);                       /* synchronise the calling thread's library stream */
+
+/* ---- a6/a8/a9/a11: window -> real FFT -> |Y| (-> dB) -> dominant peak, batched ----------------
+ * Replaces, per frame:  Y = fft(y*w); np.abs(Y); np.argmax(...)   (main.py:475, 479, 1029, 1627)
+ * computed as an rfft: bins 0..n/2 (the reference's length-n fftshift layout is rebuilt by the
+ * shim from Hermitian symmetry).  Unnormalised forward DFT, e^{-2 pi i k n/N}, like scipy.fft.fft.
+ *   x         [batch][n]        real frames
+ *   mag       [batch][n/2+1]    |Y| (or dB), only if SA_F_WRITE_MAG; may be NULL otherwise
+ *   peak_bin  [batch]           argmax_k |Y[k]|, lowest k on ties (np.argmax semantics)
+ *   peak_mag  [batch]           |Y[peak_bin]| (always linear)
+ * n: power of two, 16 <= n <= 32768 (f32) / 16384 (f64) run in one LDS-resident pass;
+ *    other n are served by sa_fft_mag_f64 (any n).                                               */
+int sa_rfft_peak_f32(const float* x, int64_t batch, int32_t n, int32_t window, double win_param,
+                     int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag);
+int sa_rfft_peak_f64(const double* x, int64_t batch, int32_t n, int32_t window, double win_param,
+                     int32_t flags, double* mag, int32_t* peak_bin, double* peak_mag);
+int sa_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param,
+                         int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, void* stream);
+int sa_rfft_peak_f64_dev(const double* x, int64_t batch, int32_t n, int32_t window, double win_param,
+                         int32_t flags, double* mag, int32_t* peak_bin, double* peak_mag, void* stream);
+
+/* Run `iters` back-to-back launches of sa_rfft_peak_f32_dev on the library stream and return the
+ * average kernel time in milliseconds measured with HIP events on that same stream (bench.py's
+ * roofline leg; no counterpart in the reference, which has one time.time() log line, sab10.py:614). */
+int sa_time_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param,
+                              int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag,
+                              int32_t iters, float* ms_avg);
+
+/* Synthetic benchmark frames generated on the device:
+ * frame b: A_b sin(2 pi f_b n/fs + phi_b) + 0.01 N(0,1), counter-based RNG keyed by (seed, b, n).
+ * Same formula is restated on the host in oracle/ for parity tests. */
+int sa_fill_tone_noise_f32_dev(float* x, int64_t batch, int32_t n, double fs, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECENGINE_H */

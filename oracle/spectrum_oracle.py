@@ -1,0 +1,316 @@
+"""CPU oracle for the spectrum-analysis hot path — TEST INFRASTRUCTURE ONLY.
+
+This is a numpy restatement of the arithmetic the reference performs on the hot path
+(Gecesars/FFT main.py / versão15.py).  It exists so that tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg can check / time the CPU path.  Nothing under fft_amd/ may import it.
+
+Where the arithmetic lives: the reference calls third-party numpy / scipy (pinned numpy==2.3.2,
+scipy==1.16.0 in requirements.txt:8,13; 2.2.6 / 1.15.3 are installed here).  FFTs use numpy's
+pocketfft (the same algorithm as scipy.fft.fft used at main.py:475); the scipy.signal waveform
+helpers (square / sawtooth / chirp / gausspulse / unit_impulse) are restated below from their
+published formulas (scipy/signal/_waveforms.py) so the HIP generators have an explicit model.
+
+Pinning: tests/test_oracle_golden.py checks every function here against tests/golden/*.npz, which
+tools/gen_golden.py produced by calling the reference's own methods (loaded from
+/root/reference/main.py with GUI stubs) in the build container.
+"""
+import numpy as np
+import scipy.fft as sfft
+
+TWO_PI = 2 * np.pi
+
+# ---- a1: input validation (main.py:490-534) -------------------------------------------------------
+UNIT_MULTIPLIERS = {"Hz": 1, "kHz": 1e3, "MHz": 1e6, "GHz": 1e9}   # main.py:28
+
+
+def validate_inputs(duration, Fc, Fs, Fm, waveform, am_on=False, am_depth=0.5, fm_on=False, fm_dev=50.0):
+    """main.py:492-522. Raises ValueError with the reference's messages."""
+    p = {"duration": float(duration), "Fc": float(Fc), "Fs": float(Fs), "Fm": float(Fm),
+         "waveform": waveform, "am_on": am_on, "am_depth": am_depth, "fm_on": fm_on, "fm_dev": fm_dev}
+    if p["duration"] <= 0:
+        raise ValueError("Duração deve ser maior que zero.")
+    if p["Fs"] <= 0:
+        raise ValueError("Taxa de amostragem deve ser maior que zero.")
+    p["N"] = int(p["duration"] * p["Fs"])
+    if p["N"] < 16:
+        raise ValueError("Combinação de duração e Fs resulta em poucos pontos (< 16).")
+    if p["N"] % 2 != 0:
+        p["N"] += 1
+    max_freq = max(p["Fc"], p["Fm"])
+    if max_freq >= p["Fs"] / 2:
+        raise ValueError(
+            f"Nyquist violado! Máxima frequência ({max_freq}Hz) deve ser < Fs/2 ({p['Fs'] / 2}Hz).")
+    return p
+
+
+# ---- scipy.signal._waveforms restated -----------------------------------------------------------------
+def _sawtooth(x, width=1.0):
+    """scipy.signal.sawtooth (_waveforms.py:16): rises -1 -> 1 on [0, 2 pi w), falls 1 -> -1 after."""
+    x = np.asarray(x, dtype=np.float64)
+    tmod = np.mod(x, TWO_PI)
+    y = np.empty_like(x)
+    up = tmod < width * TWO_PI
+    with np.errstate(divide="ignore", invalid="ignore"):
+        y[up] = tmod[up] / (np.pi * width) - 1
+        dn = ~up
+        y[dn] = (np.pi * (width + 1) - tmod[dn]) / (np.pi * (1 - width))
+    return y
+
+
+def _square(x, duty=0.5):
+    """scipy.signal.square (_waveforms.py:88): +1 while (x mod 2 pi) < duty * 2 pi, else -1."""
+    x = np.asarray(x, dtype=np.float64)
+    tmod = np.mod(x, TWO_PI)
+    return np.where(tmod < duty * TWO_PI, 1.0, -1.0)
+
+
+def _chirp(t, f0, t1, f1, method):
+    """scipy.signal.chirp phase (_waveforms.py:_chirp_phase), phi=0, vertex_zero=True."""
+    t = np.asarray(t, dtype=np.float64)
+    if method == "linear":
+        beta = (f1 - f0) / t1
+        phase = TWO_PI * (f0 * t + 0.5 * beta * t * t)
+    elif method == "quadratic":
+        beta = (f1 - f0) / (t1 ** 2)
+        phase = TWO_PI * (f0 * t + beta * t ** 3 / 3)
+    else:
+        raise ValueError(method)
+    return np.cos(phase)
+
+
+def _gausspulse(t, fc, bw=0.5, bwr=-6):
+    """scipy.signal.gausspulse (_waveforms.py:163), real part only."""
+    ref = 10.0 ** (bwr / 20.0)
+    a = -(np.pi * fc * bw) ** 2 / (4.0 * np.log(ref))
+    return np.exp(-a * t * t) * np.cos(TWO_PI * fc * t)
+
+
+def _unit_impulse_mid(n):
+    y = np.zeros(n)
+    y[n // 2] = 1.0
+    return y
+
+
+# ---- a3: waveform synthesis (main.py:536-615) -------------------------------------------------------
+def generate_waveform(p, t, rng=None):
+    wf, Fc, Fm, duration = p["waveform"], p["Fc"], p["Fm"], p["duration"]
+    x = TWO_PI * Fc * t
+    with np.errstate(all="ignore"):
+        if wf == "Seno":
+            return np.sin(x)
+        if wf == "Cosseno":
+            return np.cos(x)
+        if wf == "Quadrada":
+            return _square(x)
+        if wf == "Triangular":
+            return _sawtooth(x, 0.5)
+        if wf == "Dente de Serra":
+            return _sawtooth(x)
+        if wf == "Pulso":
+            return _square(x, duty=0.2)
+        if wf == "Ruído Branco":                      # main.py:553 (unseeded global RNG: statistical parity only)
+            rng = rng or np.random.default_rng()
+            return rng.normal(0, 0.5, p["N"])
+        if wf == "Exp Decaimento":
+            return np.exp(-t / (duration / 5)) * np.sin(x)
+        if wf == "Passo (step)":
+            return np.heaviside(t - t[p["N"] // 4], 1.0)
+        if wf == "Rampa":
+            return t / t[-1]
+        if wf == "Parábola":
+            return (t / t[-1]) ** 2
+        if wf == "Impulso":
+            return _unit_impulse_mid(p["N"])
+        if wf == "Tangente":
+            return np.clip(np.tan(np.pi * Fc * t), -10, 10)
+        if wf == "Sinc":
+            return np.sinc(2 * Fc * t)
+        if wf == "Gaussiana":
+            return np.exp(-(t - t.mean()) ** 2 / (0.1 * duration) ** 2) * np.sin(x)
+        if wf == "Chirp Linear":
+            return _chirp(t, Fc, t[-1], 5 * Fc, "linear")
+        if wf == "Chirp Quadrático":
+            return _chirp(t, Fc, t[-1], 10 * Fc, "quadratic")
+        if wf == "Onda AM":
+            return (1 + 0.5 * np.sin(TWO_PI * Fm * t)) * np.sin(x)
+        if wf == "Onda FM":
+            return np.sin(x + 5 * np.sin(TWO_PI * Fm * t))
+        if wf == "Batimento":
+            return np.sin(x) + np.sin(TWO_PI * (Fc + Fm) * t)
+        if wf == "Lorentziana":
+            return 1 / (1 + x ** 2)
+        if wf == "Hiperbólica":
+            return np.sinh(x)
+        if wf == "Bessel":
+            from scipy.special import jv               # third-party, as the reference (main.py:588)
+            return jv(0, x)
+        if wf == "Sinc Modulado":
+            return np.sinc(2 * Fc * t) * np.sin(TWO_PI * Fm * t)
+        if wf == "Pulso Gaussiano":
+            return _gausspulse(t, Fc, 0.5)
+        if wf == "Dente de Serra Modificado":
+            return _sawtooth(x, 0.3)
+        if wf == "Onda AM-DSB":
+            return np.sin(x) * np.sin(TWO_PI * Fm * t)
+        if wf == "Onda FM Estéreo":
+            m = 3 * np.sin(TWO_PI * Fm * t)
+            return 0.5 * (np.sin(x + m) + np.sin(TWO_PI * (Fc + 1000) * t + m))
+        if wf == "Onda Quadrada Modulada":
+            return _square(x) * (1 + 0.5 * np.sin(TWO_PI * Fm * t))
+        if wf == "Onda Triangular Modulada":
+            return _sawtooth(x, 0.5) * (1 + 0.3 * np.sin(TWO_PI * Fm * t))
+        if wf == "Pulso Exponencial":
+            return np.exp(-5 * t / duration) * np.sin(x)
+        if wf == "Onda Comb":
+            return np.sign(np.sin(x) + 0.7)
+        if wf == "Onda Harmônica":
+            return np.sin(x) + 0.5 * np.sin(TWO_PI * 2 * Fc * t)
+    return np.zeros_like(t)                           # main.py:614-615
+
+
+# ---- a5: modulation (main.py:617-629) ---------------------------------------------------------------
+def apply_modulation(p, y, t):
+    if p["am_on"]:
+        y = y * (1 + p["am_depth"] * np.sin(TWO_PI * p["Fm"] * t))
+    if p["fm_on"]:   # replaces y (amplitude reset to 1: reference quirk, main.py:625-627)
+        phase = TWO_PI * p["Fc"] * t + TWO_PI * p["fm_dev"] * np.cumsum(np.sin(TWO_PI * p["Fm"] * t)) * (1 / p["Fs"])
+        y = np.sin(phase)
+    return y
+
+
+# ---- a6/a7/a8: _calculate_fft (main.py:959-965) -----------------------------------------------------
+def calculate_fft(t, y):
+    N = len(y)
+    Fs = 1 / (t[1] - t[0]) if len(t) > 1 else 1
+    # scipy.fft.fft, like the reference (main.py:9): for real input pocketfft runs an r2c transform and
+    # mirrors it, so |Y| is EXACTLY symmetric and np.argmax lands on the negative-frequency twin.
+    Y = sfft.fftshift(sfft.fft(np.asarray(y, dtype=np.float64)))
+    f = sfft.fftshift(sfft.fftfreq(N, 1 / Fs))
+    return f, np.abs(Y)
+
+
+def compute(p, vpp=None):
+    """main.py:460-479 -> the `last_data` dict."""
+    t = np.arange(p["N"]) / p["Fs"]
+    y = generate_waveform(p, t)
+    if vpp is not None:
+        y = y * (vpp / 2)
+    if not p["waveform"].startswith("Onda AM") and not p["waveform"].startswith("Onda FM"):
+        y = apply_modulation(p, y, t)
+    Y = sfft.fftshift(sfft.fft(y))
+    f = sfft.fftshift(sfft.fftfreq(p["N"], 1 / p["Fs"]))
+    return {"t": t, "y": y, "f": f, "Y": np.abs(Y)}
+
+
+# ---- a9: dominant peak (main.py:1029-1031 full array; 1622-1629 f>0 mask) ---------------------------
+def dominant_peak(f, Y, positive_only=False):
+    f = np.asarray(f)
+    Y = np.asarray(Y)
+    if positive_only:
+        m = f > 0
+        fp, Yp = f[m], Y[m]
+        i = int(np.argmax(Yp))
+        return i, float(fp[i]), float(Yp[i])
+    i = int(np.argmax(Y))
+    return i, float(f[i]), float(Y[i])
+
+
+# ---- a11: windows (numpy / scipy symmetric definitions; firmware Core/Src/main.c:83-99 agrees) ------
+def window(kind, n, param=0.0):
+    kind = (kind or "none").lower() if not isinstance(kind, int) else kind
+    names = {0: "none", 1: "hann", 2: "hamming", 3: "blackman", 4: "gaussian"}
+    kind = names.get(kind, kind)
+    if kind in ("none", "rect", "boxcar"):
+        return np.ones(n)
+    if kind in ("hann", "hanning"):
+        return np.hanning(n)
+    if kind == "hamming":
+        return np.hamming(n)
+    if kind == "blackman":
+        return np.blackman(n)
+    if kind in ("gaussian", "gauss"):
+        std = param if param and param > 0 else (n - 1) / 5.0
+        k = np.arange(n) - (n - 1) / 2.0
+        return np.exp(-0.5 * (k / std) ** 2)          # scipy.signal.windows.gaussian(n, std, sym=True)
+    raise ValueError(kind)
+
+
+DB_FLOOR = {np.dtype(np.float32): 1e-30, np.dtype(np.float64): 1e-300}
+
+
+def rfft_mag_peak(x, win="hann", win_param=0.0, db=False, exclude_dc_nyq=False):
+    """Batched model of the fused kernel: fp64 pocketfft on the (dtype-exact) input samples.
+    x: [batch, n].  Returns (mag f64 [batch, n/2+1], peak_bin int64 [batch], peak_mag f64 [batch])."""
+    x = np.atleast_2d(np.asarray(x))
+    n = x.shape[1]
+    w = window(win, n, win_param)
+    Y = np.abs(np.fft.rfft(x.astype(np.float64) * w, axis=1))
+    S = Y.copy()
+    if exclude_dc_nyq:
+        S[:, 0] = -1
+        if n % 2 == 0:
+            S[:, -1] = -1
+    pb = np.argmax(S, axis=1)
+    pm = Y[np.arange(Y.shape[0]), pb]
+    if db:
+        Y = 20 * np.log10(np.maximum(Y, DB_FLOOR[np.dtype(x.dtype)] if x.dtype in (np.float32, np.float64) else 1e-300))
+    return Y, pb, pm
+
+
+def top2_gap(mag, exclude_dc_nyq=False):
+    """Relative gap between the largest and second largest magnitude per frame (peak-tie guard)."""
+    S = np.array(mag, dtype=np.float64, copy=True)
+    if exclude_dc_nyq:
+        S[:, 0] = -1
+        S[:, -1] = -1
+    part = np.partition(S, -2, axis=1)
+    return (part[:, -1] - part[:, -2]) / np.maximum(part[:, -1], 1e-300)
+
+
+# ---- a10: not-a-knot cubic spline (scipy.interpolate.CubicSpline default, main.py:1390-1392) --------
+def cubic_spline_notaknot(xk, yk, xq):
+    """Restatement of scipy's CubicSpline(x, y)(xq) with bc_type='not-a-knot' (scipy/interpolate/_cubic.py:
+    the tridiagonal system for the knot derivatives s_i with the two not-a-knot boundary rows),
+    solved densely here (small n); evaluation in the local Hermite/power basis like PPoly."""
+    xk = np.asarray(xk, dtype=np.float64)
+    yk = np.asarray(yk, dtype=np.float64)
+    n = len(xk)
+    dx = np.diff(xk)
+    slope = np.diff(yk) / dx
+    if n == 2:
+        s = np.array([slope[0], slope[0]])
+    elif n == 3:
+        # scipy: parabola through the 3 points
+        A = np.zeros((3, 3)); b = np.zeros(3)
+        A[0, 0] = 1; A[0, 1] = 1
+        A[1, 0] = dx[1]; A[1, 1] = 2 * (dx[0] + dx[1]); A[1, 2] = dx[0]
+        A[2, 1] = 1; A[2, 2] = 1
+        b[0] = 2 * slope[0]
+        b[1] = 3 * (dx[0] * slope[1] + dx[1] * slope[0])
+        b[2] = 2 * slope[1]
+        s = np.linalg.solve(A, b)
+    else:
+        A = np.zeros((n, n)); b = np.zeros(n)
+        for i in range(1, n - 1):
+            A[i, i - 1] = dx[i]
+            A[i, i] = 2 * (dx[i - 1] + dx[i])
+            A[i, i + 1] = dx[i - 1]
+            b[i] = 3 * (dx[i] * slope[i - 1] + dx[i - 1] * slope[i])
+        A[0, 0] = dx[1]
+        A[0, 1] = xk[2] - xk[0]
+        d = xk[2] - xk[0]
+        b[0] = ((dx[0] + 2 * d) * dx[1] * slope[0] + dx[0] ** 2 * slope[1]) / d
+        A[-1, -1] = dx[-2]
+        A[-1, -2] = xk[-1] - xk[-3]
+        d = xk[-1] - xk[-3]
+        b[-1] = (dx[-1] ** 2 * slope[-2] + (2 * d + dx[-1]) * dx[-2] * slope[-1]) / d
+        s = np.linalg.solve(A, b)
+    tt = (s[:-1] + s[1:] - 2 * slope) / dx
+    c3 = tt / dx
+    c2 = (slope - s[:-1]) / dx - tt
+    c1 = s[:-1]
+    c0 = yk[:-1]
+    xq = np.asarray(xq, dtype=np.float64)
+    idx = np.clip(np.searchsorted(xk, xq, side="right") - 1, 0, n - 2)
+    h = xq - xk[idx]
+    return ((c3[idx] * h + c2[idx]) * h + c1[idx]) * h + c0[idx]

@@ -1,0 +1,146 @@
+"""GPU parity: fused window->rfft->|Y|->peak kernels vs the CPU oracle, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import spectrum_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-300)
+
+
+def check_peaks(pb, pm, mag_ref, pb_ref, excl=False, tie_rel=1e-5):
+    """Peak bins must be identical to np.argmax on the oracle spectrum; a frame whose oracle top-2
+    relative gap is below `tie_rel` (f32 rounding can legitimately flip it) must match one of the two."""
+    bad = np.nonzero(pb != pb_ref)[0]
+    if len(bad):
+        gap = O.top2_gap(mag_ref[bad], excl)
+        assert (gap < tie_rel).all(), f"peak mismatch on frames {bad[:8]} gaps {gap[:8]}"
+
+
+@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("win", ["none", "hann", "hamming", "blackman", "gaussian"])
+def test_rfft_f32_all_sizes(n, win):
+    import fft_amd
+    rng = np.random.default_rng(n * 7 + len(win))
+    batch = 37 if n <= 4096 else 5
+    t = np.arange(n)
+    f0 = rng.uniform(1, n / 2 - 1, size=(batch, 1))
+    x = (np.sin(2 * np.pi * f0 * t / n + rng.uniform(0, 6, (batch, 1))) + 0.1 * rng.standard_normal((batch, n))).astype(np.float32)
+    mag, pb, pm = fft_amd.rfft_peak(x, win)
+    mref, pbref, pmref = O.rfft_mag_peak(x, win)
+    tol = 1e-5 * np.log2(n)                       # north_star: fp32 within 1e-5*log2(N) relative L2
+    assert rel_l2(mag, mref).max() < tol
+    check_peaks(pb, pm, mref, pbref)
+    np.testing.assert_allclose(pm, pmref, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n", [16, 64, 256, 1024, 4096, 16384])
+@pytest.mark.parametrize("win", ["none", "hamming", "gaussian"])
+def test_rfft_f64_all_sizes(n, win):
+    import fft_amd
+    rng = np.random.default_rng(n + 1)
+    batch = 9
+    x = rng.standard_normal((batch, n)) + np.sin(2 * np.pi * 0.123 * np.arange(n))
+    mag, pb, pm = fft_amd.rfft_peak(x, win)
+    mref, pbref, pmref = O.rfft_mag_peak(x, win)
+    # north_star: fp64 spectra within 1e-12 relative (to the frame's largest magnitude)
+    assert (np.abs(mag - mref).max(axis=1) / mref.max(axis=1)).max() < 1e-12
+    assert rel_l2(mag, mref).max() < 1e-12
+    np.testing.assert_array_equal(pb, pbref)
+    np.testing.assert_allclose(pm, pmref, rtol=1e-12)
+
+
+def test_config1_hamming_peak(golden_dir):
+    """BASELINE config 1: 10 kHz sine @ 100 kHz, N=4096, Hamming -> rfft bin 410, |Y| = 972.569..."""
+    import fft_amd
+    z = np.load(os.path.join(golden_dir, "config1.npz"))
+    mag, pb, pm = fft_amd.rfft_peak(z["y"], "hamming")
+    assert pb == 410
+    assert pm == pytest.approx(972.5694252172681, rel=1e-12)
+    assert np.abs(mag - z["Y_hamming_rfft"]).max() / 972.57 < 1e-12
+    mag32, pb32, pm32 = fft_amd.rfft_peak(z["y"].astype(np.float32), "hamming")
+    assert pb32 == 410 and pm32 == pytest.approx(972.5694, rel=1e-5)
+
+
+def test_flags_db_exclude_and_peak_only():
+    import fft_amd
+    n = 1024
+    x = np.ones((3, n), dtype=np.float32) * 2.0 + 0.5 * np.cos(2 * np.pi * 100 * np.arange(n) / n).astype(np.float32)
+    mag, pb, pm = fft_amd.rfft_peak(x, "none")
+    assert (pb == 0).all()
+    mag, pb, pm = fft_amd.rfft_peak(x, "none", exclude_dc_nyq=True)
+    assert (pb == 100).all() and pm[0] == pytest.approx(0.25 * n, rel=1e-5)
+    magdb, pb2, pm2 = fft_amd.rfft_peak(x, "none", db=True, exclude_dc_nyq=True)
+    ref, _, _ = O.rfft_mag_peak(x, "none", db=False)
+    sel = ref > 1e-3
+    np.testing.assert_allclose(magdb[sel], 20 * np.log10(ref[sel]), atol=1e-3)
+    assert (pb2 == 100).all() and pm2[0] == pytest.approx(0.25 * n, rel=1e-5)      # peak_mag stays linear
+    none_mag, pb3, pm3 = fft_amd.rfft_peak(x, "none", write_mag=False, exclude_dc_nyq=True)
+    assert none_mag is None and (pb3 == 100).all()
+
+
+def test_kats_impulse_dc_nyquist_ties():
+    import fft_amd
+    n = 4096
+    x = np.zeros((4, n), dtype=np.float32)
+    x[0, 0] = 1.0                        # impulse at 0 -> all ones, argmax tie -> bin 0
+    x[1, :] = 1.0                        # DC
+    x[2, ::2] = 1.0; x[2, 1::2] = -1.0   # Nyquist
+    x[3, 123] = 1.0                      # shifted impulse: flat magnitude 1
+    mag, pb, pm = fft_amd.rfft_peak(x, "none")
+    np.testing.assert_array_equal(mag[0], np.ones(n // 2 + 1, dtype=np.float32))
+    assert pb[0] == 0 and pb[1] == 0 and pb[2] == n // 2
+    assert pm[1] == n and pm[2] == n
+    np.testing.assert_allclose(mag[3], 1.0, atol=1e-5)
+
+
+def test_bad_arguments_raise_valueerror():
+    import fft_amd
+    with pytest.raises(ValueError):
+        fft_amd.rfft_peak(np.zeros((2, 1000), np.float32))        # not a power of two
+    with pytest.raises(ValueError):
+        fft_amd.rfft_peak(np.zeros((2, 8), np.float32))           # < 16 (main.py:512)
+    with pytest.raises(ValueError):
+        fft_amd.rfft_peak(np.zeros((2, 64), np.float32), "kaiser")
+    mag, pb, pm = fft_amd.rfft_peak(np.zeros((0, 64), np.float32))  # empty batch is fine
+    assert mag.shape == (0, 33) and pb.shape == (0,)
+
+
+def test_large_batch_device_resident_properties():
+    """Full-shape property checks (BASELINE config 2 shape, reduced batch that still spans >1 wave of
+    workgroups): device-generated tone+noise frames; sampled frames vs oracle; peak == argmax(mag)."""
+    import ctypes as C
+    from fft_amd import _lib
+    lib = _lib.load()
+    n, batch = 4096, 20000
+    dx = _lib.DeviceBuffer(batch * n * 4)
+    dm = _lib.DeviceBuffer(batch * (n // 2 + 1) * 4)
+    dpb = _lib.DeviceBuffer(batch * 4)
+    dpm = _lib.DeviceBuffer(batch * 4)
+    _lib.check(lib.sa_fill_tone_noise_f32_dev(dx.ptr, batch, n, 100e3, 0x5EED0002, None))
+    _lib.check(lib.sa_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, _lib.F_WRITE_MAG, dm.ptr, dpb.ptr, dpm.ptr, None))
+    _lib.check(lib.sa_sync())
+    x = np.empty((batch, n), np.float32); dx.download(x)
+    mag = np.empty((batch, n // 2 + 1), np.float32); dm.download(mag)
+    pb = np.empty(batch, np.int32); dpb.download(pb)
+    pm = np.empty(batch, np.float32); dpm.download(pm)
+    assert np.isfinite(x).all() and 0.3 < np.abs(x).max() < 1.2
+    np.testing.assert_array_equal(pb, np.argmax(mag, axis=1))       # kernel's own spectrum <-> its peak
+    np.testing.assert_array_equal(pm, mag[np.arange(batch), pb])
+    sel = np.r_[0:64, batch - 64:batch, np.random.default_rng(1).integers(0, batch, 256)]
+    mref, pbref, _ = O.rfft_mag_peak(x[sel], "hann")
+    assert rel_l2(mag[sel], mref).max() < 1e-5 * 12
+    check_peaks(pb[sel], pm[sel], mref, pbref)
+    # peak-only mode gives identical peaks
+    _lib.check(lib.sa_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, 0, None, dpb.ptr, dpm.ptr, None))
+    _lib.check(lib.sa_sync())
+    pb2 = np.empty(batch, np.int32); dpb.download(pb2)
+    np.testing.assert_array_equal(pb, pb2)
+    for b in (dx, dm, dpb, dpm):
+        b.free()
