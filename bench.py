@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric):
+windowed rFFT spectra/s + achieved HBM GB/s for the 4096-point batch (config C2:
+fp32 Hann-windowed rfft, 2^20 frames x 4096 points + per-frame peak, per GPU).
+
+One "step" = one pass of the fused window->rfft->|Y|->peak kernel over the whole device-resident
+batch (mode A: spectrum + peak written).  N>1: one process per GPU (torchrun), frames sharded by
+rank with no data-path collective (weak scaling: 2^20 frames per GPU); torch.distributed is used
+only for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+N_POINTS = 4096
+ALG_BYTES_A = N_POINTS * 4 + (N_POINTS // 2 + 1) * 4 + 8      # 24 588 B / frame (mode A)
+ALG_BYTES_B = N_POINTS * 4 + 8                                 # 16 392 B / frame (mode B, peak only)
+HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(x_sample, budget_s=12.0):
+    """Reference call pattern timed on this host:
+    CPU-ref-1T: per frame np.abs(scipy.fft.fft(y*w)) + np.argmax, fp64, 1 thread (main.py:475-479, 1029);
+    CPU-best:   batched scipy.fft.rfft(workers=-1) fp32 + abs + argmax on all cores."""
+    import scipy.fft as sfft
+    from oracle import spectrum_oracle as O
+    n = x_sample.shape[1]
+    w = O.window("hann", n)
+    x64 = x_sample.astype(np.float64)
+    # 1 thread, reference pattern
+    t0 = time.perf_counter(); cnt = 0
+    while time.perf_counter() - t0 < budget_s / 3:
+        for i in range(256):
+            Y = np.abs(sfft.fft(x64[(cnt + i) % len(x64)] * w))
+            int(np.argmax(Y))
+        cnt += 256
+    ref1t = cnt / (time.perf_counter() - t0)
+    # all cores, batched fp32 rfft
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores_used = min(ncores, 16)
+    w32 = w.astype(np.float32)
+    chunk = x_sample[:2048]
+    t0 = time.perf_counter(); cnt = 0
+    while time.perf_counter() - t0 < budget_s * 2 / 3:
+        Y = np.abs(sfft.rfft(chunk * w32, axis=1, workers=ncores_used))
+        Y.argmax(axis=1)
+        cnt += len(chunk)
+    best = cnt / (time.perf_counter() - t0)
+    return {"value": best, "unit": "spectra/s", "cores": ncores_used, "kind": "port",
+            "sample": f"{len(chunk)}-frame chunks of the same device-generated C2 frames, scipy.fft.rfft fp32 workers={ncores_used} "
+                      f"+abs+argmax for ~{budget_s * 2 / 3:.0f}s; reference 1-thread fp64 fft pattern = {ref1t:.0f} spectra/s",
+            "ref_1thread_fp64": ref1t, "host_cpus_visible": ncores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-batch", type=int, default=20, help="frames per GPU = 2^k (default 2^20 = config C2)")
+    ap.add_argument("--peak-only", action="store_true", help="mode B: no spectrum written")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from fft_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.sa_init(local_rank))
+
+    n = N_POINTS
+    batch = 1 << args.log2_batch
+    flags = 0 if args.peak_only else _lib.F_WRITE_MAG
+    dx = _lib.DeviceBuffer(batch * n * 4)
+    dm = _lib.DeviceBuffer(batch * (n // 2 + 1) * 4)
+    dpb = _lib.DeviceBuffer(batch * 4)
+    dpm = _lib.DeviceBuffer(batch * 4)
+    seed = 0x5EED0002 + rank
+    _lib.check(lib.sa_fill_tone_noise_f32_dev(dx.ptr, batch, n, 100e3, seed, None))
+    _lib.check(lib.sa_sync())
+
+    def step():
+        _lib.check(lib.sa_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, flags, dm.ptr, dpb.ptr, dpm.ptr, None))
+
+    def barrier():
+        _lib.check(lib.sa_sync())
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.sa_sync())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    # roofline leg: HIP events on the library stream around `steps` back-to-back launches
+    import ctypes as C
+    ms = C.c_float(0)
+    _lib.check(lib.sa_time_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, flags, dm.ptr, dpb.ptr, dpm.ptr,
+                                              max(args.steps, 5), C.byref(ms)))
+    alg = ALG_BYTES_B if args.peak_only else ALG_BYTES_A
+    achieved = alg * batch / (ms.value * 1e-3) / 1e9
+
+    if rank == 0:
+        # sanity: a sample of frames vs the CPU oracle (not timed)
+        from oracle import spectrum_oracle as O
+        ns = 256
+        xs = np.empty((ns, n), np.float32); dx.download(xs, ns * n * 4)
+        pbs = np.empty(ns, np.int32); dpb.download(pbs, ns * 4)
+        mref, pbref, _ = O.rfft_mag_peak(xs, "hann")
+        parity_ok = bool((pbs == pbref).all())
+        if not args.peak_only:
+            ms_ = np.empty((ns, n // 2 + 1), np.float32); dm.download(ms_, ms_.nbytes)
+            err = float((np.linalg.norm(ms_ - mref, axis=1) / np.linalg.norm(mref, axis=1)).max())
+            parity_ok = parity_ok and err < 1e-5 * 12
+        out = {
+            "metric": "windowed rFFT spectra/s (4096-pt fp32 Hann, spectrum+peak)" if not args.peak_only
+                      else "windowed rFFT spectra/s (4096-pt fp32 Hann, peak only)",
+            "value": batch * world * args.steps / elapsed,
+            "unit": "spectra/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2: batched fp32 Hann-windowed rfft, {batch} frames x {n} points per GPU + per-frame peak"
+                                   f" ({'peak only' if args.peak_only else 'spectrum+peak'}), device-resident",
+                       "frames_per_gpu": batch, "n": n, "window": "hann", "parallelism": f"frame-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_frame": alg, "kernel_ms": ms.value},
+            "parity_sample_ok": parity_ok,
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(xs if ns >= 2048 else _more_frames(dx, n))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _more_frames(dx, n, ns=2048):
+    xs = np.empty((ns, n), np.float32)
+    dx.download(xs, ns * n * 4)
+    return xs
+
+
+if __name__ == "__main__":
+    main()
