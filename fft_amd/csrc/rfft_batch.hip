@@ -1,7 +1,9 @@
 // rfft_batch.hip — C ABI + dispatch for the batched window->rfft->|Y|->peak path.
+#include <stdlib.h>
 #include <vector>
 
 #include "rfft_generic.h"
+#include "rfft4096.h"
 #include "runtime.h"
 
 namespace sa {
@@ -31,11 +33,38 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     return SA_OK;
 }
 
+template <int MODE>
+static int launch_r4k(const RfftArgs<float>& a, hipStream_t st) {
+    auto kern = rfft4096_wave_kernel<MODE>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R4K_LDS_BYTES));
+        attr_set = true;
+    }
+    const int64_t need = (a.batch + R4K_WAVES - 1) / R4K_WAVES;
+    const int64_t cap = num_cus();                    // persistent: one 16-wave workgroup per CU
+    const int grid = (int)(need < cap ? need : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(R4K_WAVES * 64), R4K_LDS_BYTES, st, a.x, a.batch, a.win, a.twM, a.twN,
+                       (a.flags & SA_F_EXCLUDE_DC_NYQ) ? 1 : 0, a.mag, a.peak_bin, a.peak_mag, a.db_floor);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+static bool use_generic_only() {
+    static const bool v = getenv("SA_FORCE_GENERIC") != nullptr;
+    return v;
+}
+
 template <typename T>
 static int dispatch_generic(int log2n, const RfftArgs<T>& a, hipStream_t st);
 
 template <>
 int dispatch_generic<float>(int log2n, const RfftArgs<float>& a, hipStream_t st) {
+    if (log2n == 12 && !use_generic_only()) {
+        const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
+        if (!wmag) return launch_r4k<0>(a, st);
+        return (a.flags & SA_F_DB) ? launch_r4k<2>(a, st) : launch_r4k<1>(a, st);
+    }
     switch (log2n) {
         case 4: return launch_generic<float, 3, 8>(a, st);
         case 5: return launch_generic<float, 4, 8>(a, st);
