@@ -22,13 +22,18 @@
 //   * Workgroups are persistent (one 1024-thread workgroup per CU), waves stride over frames.
 // HBM traffic per frame = 16 KiB read + 8196 B (+8 B) written: the algorithmic minimum.
 #pragma once
+#include <type_traits>
+
 #include "fft_core.h"
 
 namespace sa {
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
 constexpr int R4K_WAVES = 12;                       // waves per workgroup
 constexpr int R4K_SLAB_BYTES = 8 * 136 * 8;         // 8704 B private exchange slab per wave
-constexpr int R4K_LDS_BYTES = 4096 * 4 + R4K_WAVES * R4K_SLAB_BYTES;
+constexpr int R4K_LDS_BYTES = 4096 * 4 + R4K_WAVES * R4K_SLAB_BYTES + 6 * 64 * 8;
 
 __device__ __forceinline__ void wave_lds_fence() {
     // Orders this wave's LDS accesses for the compiler; the hardware executes one wave's DS
@@ -38,24 +43,27 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// p[k] = w^k for k = 1..15 (p[0] unused) with a depth-4 product tree.
-__device__ __forceinline__ void twiddle_powers16(float2 w, float2* p) {
-    p[1] = w;
-    p[2] = cmul(w, w);
-    p[3] = cmul(p[2], w);
-    p[4] = cmul(p[2], p[2]);
-    p[5] = cmul(p[4], w);
-    p[6] = cmul(p[4], p[2]);
-    p[7] = cmul(p[4], p[3]);
-    p[8] = cmul(p[4], p[4]);
-    p[9] = cmul(p[8], w);
-    p[10] = cmul(p[8], p[2]);
-    p[11] = cmul(p[8], p[3]);
-    p[12] = cmul(p[8], p[4]);
-    p[13] = cmul(p[8], p[5]);
-    p[14] = cmul(p[8], p[6]);
-    p[15] = cmul(p[8], p[7]);
+// v[k] *= w^k for k = 1..15; powers come from a depth-4 product tree and are consumed as they are
+// produced so that only w^1..w^8 stay live.
+__device__ __forceinline__ void apply_twiddles16(float2* v, float2 w) {
+    const float2 p1 = w;                 v[1] = cmul(v[1], p1);
+    const float2 p2 = cmul(w, w);        v[2] = cmul(v[2], p2);
+    const float2 p3 = cmul(p2, w);       v[3] = cmul(v[3], p3);
+    const float2 p4 = cmul(p2, p2);      v[4] = cmul(v[4], p4);
+    const float2 p5 = cmul(p4, w);       v[5] = cmul(v[5], p5);
+    const float2 p6 = cmul(p4, p2);      v[6] = cmul(v[6], p6);
+    const float2 p7 = cmul(p4, p3);      v[7] = cmul(v[7], p7);
+    const float2 p8 = cmul(p4, p4);      v[8] = cmul(v[8], p8);
+    v[9] = cmul(v[9], cmul(p8, p1));
+    v[10] = cmul(v[10], cmul(p8, p2));
+    v[11] = cmul(v[11], cmul(p8, p3));
+    v[12] = cmul(v[12], cmul(p8, p4));
+    v[13] = cmul(v[13], cmul(p8, p5));
+    v[14] = cmul(v[14], cmul(p8, p6));
+    v[15] = cmul(v[15], cmul(p8, p7));
 }
+
+__device__ __forceinline__ void stage_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // multiply by w16^i (i = 0..3), compile-time i
 template <int I> __device__ __forceinline__ float2 mul_w16(float2 a) {
@@ -80,6 +88,51 @@ __device__ __forceinline__ void herm_pair(float2 zq, float2 zm, float2 tw, float
     mb = fast_sqrt(xb.x * xb.x + xb.y * xb.y);
 }
 
+
+// exchange 1 (half PH: k1 in [8 PH, 8 PH + 8)) followed by pass 2 on the rows read back.
+template <int PH>
+__device__ __forceinline__ void exch1_pass2(const float2 (&va)[16], const float2 (&vb)[16], float2 (&c)[16],
+                                            float4* slab4, const float2* slab2, int x1_wr, int x1_rd, const float2* w2p) {
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 a = va[8 * PH + k], b = vb[8 * PH + k];
+        slab4[x1_wr + 68 * k] = make_float4(a.x, a.y, b.x, b.y);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) c[n2] = slab2[x1_rd + 8 * n2];
+    stage_fence();
+    bfly16<float>(c);
+    apply_twiddles16(c, *w2p);
+    stage_fence();
+}
+
+// exchange 2 (half Q: k2 in [8 Q, 8 Q + 8)) followed by the two radix-8 butterflies of pass 3.
+template <int Q>
+__device__ __forceinline__ void exch2_pass3(const float2 (&b0)[16], const float2 (&b1)[16], float2 (&d1)[8],
+                                            float2 (&d2)[8], const float4* slab4, float2* slab2, int x2_wr0,
+                                            int x2_wr1, int h1, int h2) {
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        slab2[x2_wr0 + 128 * k] = b0[8 * Q + k];
+        slab2[x2_wr1 + 128 * k] = b1[8 * Q + k];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 u = slab4[h1 * 4 + (c ^ ((h1 >> 2) & 3))];
+        d1[2 * c] = mk<float>(u.x, u.y); d1[2 * c + 1] = mk<float>(u.z, u.w);
+        const float4 v = slab4[h2 * 4 + (c ^ ((h2 >> 2) & 3))];
+        d2[2 * c] = mk<float>(v.x, v.y); d2[2 * c + 1] = mk<float>(v.z, v.w);
+    }
+    stage_fence();
+    bfly8<float>(d1);
+    bfly8<float>(d2);
+    stage_fence();
+}
+
 // MODE: 0 = peak only, 1 = write |Y|, 2 = write dB
 template <int MODE>
 __global__ void __launch_bounds__(R4K_WAVES * 64)
@@ -90,7 +143,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* wtab4 = reinterpret_cast<float4*>(smem_raw);                 // 1024 float4: 0.5 * window
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
     char* slab = smem_raw + 4096 * 4 + wave * R4K_SLAB_BYTES;
     float4* slab4 = reinterpret_cast<float4*>(slab);
     float2* slab2 = reinterpret_cast<float2*>(slab);
@@ -102,106 +155,92 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
     }
     __syncthreads();
 
-    // ---- per-lane constants ------------------------------------------------------------------
-    const float2 w1a = twM[2 * lane], w1b = twM[2 * lane + 1];          // w_2048^{2t}, w_2048^{2t+1}
-    const float2 w2b = twM[16 * (lane & 7)];                            // w_128^{n3}
-    const bool special = (lane == 0);
-    const int kA = special ? 128 : lane;                                 // slot-1 pair index base, i < 4
-    const int kB = special ? -768 : lane;                                // slot-1 pair index base, i >= 4
-    const int kC = 64 + lane;                                            // slot-2 pair index base
-    const float2 wA = twN[kA];
-    const float2 wB = special ? cconj(twN[768]) : wA;                    // w_4096^{-768}
-    const float2 wC = twN[kC];
-    // exchange-1 addresses
-    const int x1_wr = lane;                                              // float4 index, + 68 * k1'
-    const int x1_rd = (lane >> 3) * 136 + (lane & 7);                    // float2 index, + 8 * n2
-    // exchange-2 write addresses (float2 index), + 128 * k2'
-    const int n3 = lane & 7;
-    const int k1lo = lane >> 3, k1hi = 8 + (lane >> 3);
-    const int x2_wr0 = k1lo * 8 + ((((n3 >> 1) ^ ((k1lo >> 2) & 3)) << 1) | (n3 & 1));
-    const int x2_wr1 = k1hi * 8 + ((((n3 >> 1) ^ ((k1hi >> 2) & 3)) << 1) | (n3 & 1));
-    // exchange-2 read rows hl' (phase 0: t, t+64; phase 1: (128-t)&127, 64-t)
-    const int hl_p1 = lane, hl_p2 = lane + 64, hl_q1 = (128 - lane) & 127, hl_q2 = 64 - lane;
+    // ---- per-lane twiddle bases live in a 3 KiB LDS table (they depend on the lane only), so they
+    //      occupy no registers across the frame loop: [0] w_2048^{2t} [1] w_2048^{2t+1} [2] w_128^{t&7}
+    //      [3] wA [4] wB [5] wC (Hermitian-pass bases, see below).
+    float2* ctab = reinterpret_cast<float2*>(smem_raw + 4096 * 4 + R4K_WAVES * R4K_SLAB_BYTES);
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        ctab[0 * 64 + t] = twM[2 * t];
+        ctab[1 * 64 + t] = twM[2 * t + 1];
+        ctab[2 * 64 + t] = twM[16 * (t & 7)];
+        ctab[3 * 64 + t] = twN[t == 0 ? 128 : t];
+        ctab[4 * 64 + t] = t == 0 ? cconj(twN[768]) : twN[t];            // lane 0: w_4096^{-768}
+        ctab[5 * 64 + t] = twN[64 + t];
+    }
+    __syncthreads();
 
     const int64_t nwaves = (int64_t)gridDim.x * R4K_WAVES;
     for (int64_t frame = (int64_t)blockIdx.x * R4K_WAVES + wave; frame < batch; frame += nwaves) {
-        const float4* xf4 = reinterpret_cast<const float4*>(x + frame * 4096);
+        // Buffer descriptors rebuilt per frame from scalars: 32-bit per-lane offsets + immediates keep
+        // the address VGPRs at one per access family (no 64-bit per-lane pointers).
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(x + frame * 4096), 0, 4096 * 4, 0x00020000);
+        // The base twiddles are made opaque once per frame: otherwise LICM hoists every derived power
+        // (~140 registers of loop invariants) out of the frame loop and the allocator spills them.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                                         // lane-derived values recomputed per frame
+        const bool special = (ln == 0);
+        const int kA = special ? 128 : ln;                                   // slot-1 pair index base, i < 4
+        const int kB = special ? 256 : ln + 1024;                            // slot-1 base for i >= 4: k = kB + 256 (i - 4)
+        const int kC = 64 + ln;                                              // slot-2 pair index base
+        const int kAm = 256 - kA, kBm = special ? 1024 : 256 - ln, kCm = 256 - kC;            // mirrored: 2048 - k = kXm + 256 (7 - i)
+        const int x1_wr = ln;                                                // float4 index, + 68 * k1'
+        const int x1_rd = (ln >> 3) * 136 + (ln & 7);                        // float2 index, + 8 * n2
+        const int n3 = ln & 7;
+        const int k1lo = ln >> 3, k1hi = 8 + (ln >> 3);
+        const int x2_wr0 = k1lo * 8 + ((((n3 >> 1) ^ ((k1lo >> 2) & 3)) << 1) | (n3 & 1));   // float2 index, + 128 * k2'
+        const int x2_wr1 = k1hi * 8 + ((((n3 >> 1) ^ ((k1hi >> 2) & 3)) << 1) | (n3 & 1));
+        // exchange-2 read rows hl' (phase 0: t, t+64; phase 1: (128-t)&127, 64-t)
+        const int hl_p1 = ln, hl_p2 = ln + 64, hl_q1 = (128 - ln) & 127, hl_q2 = 64 - ln;
         float2 va[16], vb[16];
         {
             float4 r[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) r[j] = xf4[j * 64 + lane];
+            for (int j = 0; j < 16; ++j) {
+                const v4f t4 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrs, ln * 16, j * 1024, 0));
+                r[j] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+            }
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float4 w = wtab4[j * 64 + lane];
+                const float4 w = wtab4[j * 64 + ln];
                 va[j] = mk<float>(r[j].x * w.x, r[j].y * w.y);
                 vb[j] = mk<float>(r[j].z * w.z, r[j].w * w.w);
             }
         }
         // ---- pass 1: radix-16 over n1 (stride 128), twiddle w_2048^{id k1} ----------------------
+        stage_fence();
         bfly16<float>(va);
+        apply_twiddles16(va, ctab[0 * 64 + ln]);
+        stage_fence();
         bfly16<float>(vb);
-        {
-            float2 p[16];
-            twiddle_powers16(w1a, p);
-#pragma unroll
-            for (int k = 1; k < 16; ++k) va[k] = cmul(va[k], p[k]);
-            twiddle_powers16(w1b, p);
-#pragma unroll
-            for (int k = 1; k < 16; ++k) vb[k] = cmul(vb[k], p[k]);
-        }
+        apply_twiddles16(vb, ctab[1 * 64 + ln]);
+        stage_fence();
         // ---- exchange 1 + pass 2 (two halves: k1 < 8, k1 >= 8) ----------------------------------
         float2 b0[16], b1[16];
-        float2 p2[16];
-        twiddle_powers16(w2b, p2);
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float2 a = va[8 * ph + k], b = vb[8 * ph + k];
-                slab4[x1_wr + 68 * k] = make_float4(a.x, a.y, b.x, b.y);
-            }
-            wave_lds_fence();
-            float2* c = ph ? b1 : b0;
-#pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) c[n2] = slab2[x1_rd + 8 * n2];
-            bfly16<float>(c);
-#pragma unroll
-            for (int k = 1; k < 16; ++k) c[k] = cmul(c[k], p2[k]);
-        }
+        exch1_pass2<0>(va, vb, b0, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
+        exch1_pass2<1>(va, vb, b1, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
         // ---- exchange 2 + pass 3 (two halves: k2 < 8 -> hl < 128, k2 >= 8 -> hl >= 128) ---------
         float2 P1[8], P2[8], Q1[8], Q2[8];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                slab2[x2_wr0 + 128 * k] = b0[8 * q + k];
-                slab2[x2_wr1 + 128 * k] = b1[8 * q + k];
-            }
-            wave_lds_fence();
-            float2* d1 = q ? Q1 : P1;
-            float2* d2 = q ? Q2 : P2;
-            const int h1 = q ? hl_q1 : hl_p1, h2 = q ? hl_q2 : hl_p2;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 u = slab4[h1 * 4 + (c ^ ((h1 >> 2) & 3))];
-                d1[2 * c] = mk<float>(u.x, u.y); d1[2 * c + 1] = mk<float>(u.z, u.w);
-                const float4 v = slab4[h2 * 4 + (c ^ ((h2 >> 2) & 3))];
-                d2[2 * c] = mk<float>(v.x, v.y); d2[2 * c + 1] = mk<float>(v.z, v.w);
-            }
-            bfly8<float>(d1);
-            bfly8<float>(d2);
-        }
+        exch2_pass3<0>(b0, b1, P1, P2, slab4, slab2, x2_wr0, x2_wr1, hl_p1, hl_p2);
+        exch2_pass3<1>(b0, b1, Q1, Q2, slab4, slab2, x2_wr0, x2_wr1, hl_q1, hl_q2);
         wave_lds_fence();
         // ---- Hermitian post-pass ---------------------------------------------------------------
         // slot 1: (U[i], V[7-i]); generic lanes U = P1, V = Q1; lane 0 owns butterflies 0 and 128.
-        float m[34];
-        int kk[34];
-        float* mf = (MODE != 0) ? mag + frame * 2049 : nullptr;
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+            MODE != 0 ? mag + frame * 2049 : nullptr, 0, MODE != 0 ? 2049 * 4 : 0, 0x00020000);
+        unsigned long long key = 0;                     // (|Y| bits << 32) | (4095 - k): max = peak, lowest k
+        // emit |Y[kbase + koff]|: kbase is a per-lane register, koff a compile-time constant
+        auto emit = [&](float v, int kbase, int koff) {
+            const int k = kbase + koff;
+            const unsigned long long c = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(4095 - k);
+            key = c > key ? c : key;
+            if (MODE == 2) v = 20.0f * __log10f(fmaxf(v, db_floor));
+            if (MODE != 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), mrs, kbase * 4, koff * 4, 0);
+        };
         const float2 z0 = P1[0];
         {
+            const float2 wA = ctab[3 * 64 + ln], wB = ctab[4 * 64 + ln];
             float2 U[8], V[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) U[i] = special ? Q1[i] : P1[i];
@@ -211,64 +250,57 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
             for (int i = 4; i < 8; ++i) V[i] = Q1[i];
             V[3] = special ? P1[7] : Q1[3]; V[2] = special ? P1[6] : Q1[2];
             V[1] = special ? P1[5] : Q1[1]; V[0] = special ? P1[4] : Q1[0];
-            const float2 tA0 = wA, tA1 = mul_w16<1>(wA), tA2 = mul_w16<2>(wA), tA3 = mul_w16<3>(wA);
-            // i >= 4: w16^i = -i * w16^{i-4}
-            const float2 tB0 = mul_mi(wB), tB1 = mul_mi(mul_w16<1>(wB)), tB2 = mul_mi(mul_w16<2>(wB)),
-                         tB3 = mul_mi(mul_w16<3>(wB));
-            const float2 tw[8] = {tA0, tA1, tA2, tA3, tB0, tB1, tB2, tB3};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                herm_pair(U[i], V[7 - i], tw[i], m[2 * i], m[2 * i + 1]);
-                const int k = (i < 4 ? kA : kB) + 256 * i;
-                kk[2 * i] = k; kk[2 * i + 1] = 2048 - k;
-            }
+            // tw_i = w_4096^{k_i};  i >= 4: w16^i = -i * w16^{i-4}.  Twiddles are derived pair by pair so
+            // only one (tA, tB) couple is live at a time.
+            auto slot1 = [&](auto I) {
+                constexpr int i = decltype(I)::value;
+                float ma, mb;
+                herm_pair(U[i], V[7 - i], mul_w16<i>(wA), ma, mb);
+                emit(ma, kA, 256 * i);                       // k = kA + 256 i ; 2048 - k = kAm + 256 (7 - i)
+                emit(mb, kAm, 256 * (7 - i));
+                herm_pair(U[i + 4], V[3 - i], mul_mi(mul_w16<i>(wB)), ma, mb);
+                emit(ma, kB, 256 * i);                       // buffer voffsets must stay non-negative
+                emit(mb, kBm, 256 * (3 - i));
+            };
+            slot1(std::integral_constant<int, 0>{}); slot1(std::integral_constant<int, 1>{});
+            slot1(std::integral_constant<int, 2>{}); slot1(std::integral_constant<int, 3>{});
         }
+        stage_fence();
         {
-            const float2 tC0 = wC, tC1 = mul_w16<1>(wC), tC2 = mul_w16<2>(wC), tC3 = mul_w16<3>(wC);
-            const float2 tw[8] = {tC0, tC1, tC2, tC3, mul_mi(tC0), mul_mi(tC1), mul_mi(tC2), mul_mi(tC3)};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                herm_pair(P2[i], Q2[7 - i], tw[i], m[16 + 2 * i], m[16 + 2 * i + 1]);
-                const int k = kC + 256 * i;
-                kk[16 + 2 * i] = k; kk[16 + 2 * i + 1] = 2048 - k;
-            }
+            const float2 wC = ctab[5 * 64 + ln];
+            auto slot2 = [&](auto I) {
+                constexpr int i = decltype(I)::value;
+                const float2 t = mul_w16<i>(wC);
+                float ma, mb;
+                herm_pair(P2[i], Q2[7 - i], t, ma, mb);
+                emit(ma, kC, 256 * i);
+                emit(mb, kCm, 256 * (7 - i));
+                herm_pair(P2[i + 4], Q2[3 - i], mul_mi(t), ma, mb);
+                emit(ma, kC, 256 * (i + 4));
+                emit(mb, kCm, 256 * (3 - i));
+            };
+            slot2(std::integral_constant<int, 0>{}); slot2(std::integral_constant<int, 1>{});
+            slot2(std::integral_constant<int, 2>{}); slot2(std::integral_constant<int, 3>{});
         }
         // DC / Nyquist (lane 0 only): X[0] = Re Z0 + Im Z0, X[2048] = Re Z0 - Im Z0, Z0 = 2 z0
-        m[32] = fabsf(2.0f * (z0.x + z0.y));
-        m[33] = fabsf(2.0f * (z0.x - z0.y));
-        kk[32] = 0; kk[33] = 2048;
-        if (MODE != 0) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                float v = m[i];
-                if (MODE == 2) v = 20.0f * __log10f(fmaxf(v, db_floor));
-                mf[kk[i]] = v;
-            }
-            if (special) {
-                float v0 = m[32], v1 = m[33];
-                if (MODE == 2) { v0 = 20.0f * __log10f(fmaxf(v0, db_floor)); v1 = 20.0f * __log10f(fmaxf(v1, db_floor)); }
-                mf[0] = v0; mf[2048] = v1;
-            }
-        }
-        // ---- dominant peak: max, then lowest bin holding the max (np.argmax tie rule) -------------
-        float best = -1.0f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) best = fmaxf(best, m[i]);
-        if (special && !excl_dc_nyq) best = fmaxf(best, fmaxf(m[32], m[33]));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
-        int bk = 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) bk = (m[i] == best) ? min(bk, kk[i]) : bk;
-        if (special && !excl_dc_nyq) {
-            if (m[33] == best) bk = min(bk, 2048);
-            if (m[32] == best) bk = 0;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) bk = min(bk, __shfl_xor(bk, off));
         if (special) {
-            peak_bin[frame] = bk;
-            peak_mag[frame] = best;
+            const float v0 = fabsf(2.0f * (z0.x + z0.y)), v1 = fabsf(2.0f * (z0.x - z0.y));
+            const unsigned long long keep = key;
+            emit(v0, 0, 0);
+            emit(v1, 0, 2048);
+            if (excl_dc_nyq) key = keep;
+        }
+        // ---- dominant peak: wave-wide max of the packed key (np.argmax tie rule: lowest bin) -------
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned hi = __shfl_xor((unsigned)(key >> 32), off);
+            const unsigned lo = __shfl_xor((unsigned)key, off);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            key = o > key ? o : key;
+        }
+        if (special) {
+            peak_bin[frame] = 4095 - (int)(unsigned)key;
+            peak_mag[frame] = __uint_as_float((unsigned)(key >> 32));
         }
     }
 }
