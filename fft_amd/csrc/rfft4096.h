@@ -31,7 +31,7 @@ namespace sa {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-constexpr int R4K_WAVES = 12;                       // waves per workgroup
+constexpr int R4K_WAVES = 16;                       // waves per workgroup
 constexpr int R4K_SLAB_BYTES = 8 * 136 * 8;         // 8704 B private exchange slab per wave
 constexpr int R4K_LDS_BYTES = 4096 * 4 + R4K_WAVES * R4K_SLAB_BYTES + 6 * 64 * 8;
 
@@ -178,21 +178,12 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
             const_cast<float*>(x + frame * 4096), 0, 4096 * 4, 0x00020000);
         // The base twiddles are made opaque once per frame: otherwise LICM hoists every derived power
         // (~140 registers of loop invariants) out of the frame loop and the allocator spills them.
+        // Lane-derived addresses are re-derived from an opaque copy of the lane id at the stage that
+        // uses them, so they are neither hoisted out of the frame loop nor kept live across stages.
         int ln = lane;
-        asm volatile("" : "+v"(ln));                                         // lane-derived values recomputed per frame
-        const bool special = (ln == 0);
-        const int kA = special ? 128 : ln;                                   // slot-1 pair index base, i < 4
-        const int kB = special ? 256 : ln + 1024;                            // slot-1 base for i >= 4: k = kB + 256 (i - 4)
-        const int kC = 64 + ln;                                              // slot-2 pair index base
-        const int kAm = 256 - kA, kBm = special ? 1024 : 256 - ln, kCm = 256 - kC;            // mirrored: 2048 - k = kXm + 256 (7 - i)
+        asm volatile("" : "+v"(ln));
         const int x1_wr = ln;                                                // float4 index, + 68 * k1'
         const int x1_rd = (ln >> 3) * 136 + (ln & 7);                        // float2 index, + 8 * n2
-        const int n3 = ln & 7;
-        const int k1lo = ln >> 3, k1hi = 8 + (ln >> 3);
-        const int x2_wr0 = k1lo * 8 + ((((n3 >> 1) ^ ((k1lo >> 2) & 3)) << 1) | (n3 & 1));   // float2 index, + 128 * k2'
-        const int x2_wr1 = k1hi * 8 + ((((n3 >> 1) ^ ((k1hi >> 2) & 3)) << 1) | (n3 & 1));
-        // exchange-2 read rows hl' (phase 0: t, t+64; phase 1: (128-t)&127, 64-t)
-        const int hl_p1 = ln, hl_p2 = ln + 64, hl_q1 = (128 - ln) & 127, hl_q2 = 64 - ln;
         float2 va[16], vb[16];
         {
             float4 r[16];
@@ -221,12 +212,27 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
         exch1_pass2<0>(va, vb, b0, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
         exch1_pass2<1>(va, vb, b1, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
         // ---- exchange 2 + pass 3 (two halves: k2 < 8 -> hl < 128, k2 >= 8 -> hl >= 128) ---------
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        const int n3 = l2 & 7;
+        const int k1lo = l2 >> 3, k1hi = 8 + (l2 >> 3);
+        const int x2_wr0 = k1lo * 8 + ((((n3 >> 1) ^ ((k1lo >> 2) & 3)) << 1) | (n3 & 1));   // float2 index, + 128 * k2'
+        const int x2_wr1 = k1hi * 8 + ((((n3 >> 1) ^ ((k1hi >> 2) & 3)) << 1) | (n3 & 1));
+        // exchange-2 read rows hl' (phase 0: t, t+64; phase 1: (128-t)&127, 64-t)
+        const int hl_p1 = l2, hl_p2 = l2 + 64, hl_q1 = (128 - l2) & 127, hl_q2 = 64 - l2;
         float2 P1[8], P2[8], Q1[8], Q2[8];
         exch2_pass3<0>(b0, b1, P1, P2, slab4, slab2, x2_wr0, x2_wr1, hl_p1, hl_p2);
         exch2_pass3<1>(b0, b1, Q1, Q2, slab4, slab2, x2_wr0, x2_wr1, hl_q1, hl_q2);
         wave_lds_fence();
         // ---- Hermitian post-pass ---------------------------------------------------------------
         // slot 1: (U[i], V[7-i]); generic lanes U = P1, V = Q1; lane 0 owns butterflies 0 and 128.
+        int l3 = lane;
+        asm volatile("" : "+v"(l3));
+        const bool special = (l3 == 0);
+        const int kA = special ? 128 : l3;                                   // slot-1 pair index base, i < 4
+        const int kB = special ? 256 : l3 + 1024;                            // slot-1 base for i >= 4: k = kB + 256 (i - 4)
+        const int kC = 64 + l3;                                              // slot-2 pair index base
+        const int kAm = 256 - kA, kBm = special ? 1024 : 256 - l3, kCm = 256 - kC;   // mirrored: 2048 - k = kXm + 256 (7 - i)
         const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
             MODE != 0 ? mag + frame * 2049 : nullptr, 0, MODE != 0 ? 2049 * 4 : 0, 0x00020000);
         unsigned long long key = 0;                     // (|Y| bits << 32) | (4095 - k): max = peak, lowest k
@@ -240,7 +246,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
         };
         const float2 z0 = P1[0];
         {
-            const float2 wA = ctab[3 * 64 + ln], wB = ctab[4 * 64 + ln];
+            const float2 wA = ctab[3 * 64 + l3], wB = ctab[4 * 64 + l3];
             float2 U[8], V[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) U[i] = special ? Q1[i] : P1[i];
@@ -267,7 +273,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
         }
         stage_fence();
         {
-            const float2 wC = ctab[5 * 64 + ln];
+            const float2 wC = ctab[5 * 64 + l3];
             auto slot2 = [&](auto I) {
                 constexpr int i = decltype(I)::value;
                 const float2 t = mul_w16<i>(wC);
