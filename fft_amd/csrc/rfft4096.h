@@ -31,9 +31,8 @@ namespace sa {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-constexpr int R4K_WAVES = 16;                       // waves per workgroup
 constexpr int R4K_SLAB_BYTES = 8 * 136 * 8;         // 8704 B private exchange slab per wave
-constexpr int R4K_LDS_BYTES = 4096 * 4 + R4K_WAVES * R4K_SLAB_BYTES + 6 * 64 * 8;
+constexpr int r4k_lds_bytes(int waves) { return 4096 * 4 + waves * R4K_SLAB_BYTES + 6 * 64 * 8; }
 
 __device__ __forceinline__ void wave_lds_fence() {
     // Orders this wave's LDS accesses for the compiler; the hardware executes one wave's DS
@@ -63,7 +62,49 @@ __device__ __forceinline__ void apply_twiddles16(float2* v, float2 w) {
     v[15] = cmul(v[15], cmul(p8, p7));
 }
 
+// Wave-wide reductions on the VALU cross-lane path (DPP), result in every lane: 6 dependent VALU ops
+// instead of 6 LDS-latency ds_bpermute round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned old, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    unsigned u = __float_as_uint(v);     // non-negative floats order like unsigned integers
+    u = max(u, dpp_u32<0x111, 0xF>(u, u));   // row_shr:1
+    u = max(u, dpp_u32<0x112, 0xF>(u, u));   // row_shr:2
+    u = max(u, dpp_u32<0x114, 0xF>(u, u));   // row_shr:4
+    u = max(u, dpp_u32<0x118, 0xF>(u, u));   // row_shr:8   -> lane 15 of each row holds the row max
+    u = max(u, dpp_u32<0x142, 0xA>(u, u));   // row_bcast:15 into rows 1 and 3
+    u = max(u, dpp_u32<0x143, 0xC>(u, u));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the max
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u, 63));
+}
+__device__ __forceinline__ int wave_min_u32(unsigned u) {
+    u = min(u, dpp_u32<0x111, 0xF>(u, u));
+    u = min(u, dpp_u32<0x112, 0xF>(u, u));
+    u = min(u, dpp_u32<0x114, 0xF>(u, u));
+    u = min(u, dpp_u32<0x118, 0xF>(u, u));
+    u = min(u, dpp_u32<0x142, 0xA>(u, u));
+    u = min(u, dpp_u32<0x143, 0xC>(u, u));
+    return __builtin_amdgcn_readlane((int)u, 63);
+}
+
 __device__ __forceinline__ void stage_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// Diagnostic build only (tools/ubench/r4k_stamps.hip defines R4K_DIAG): per-stage s_memtime stamps.
+#ifdef R4K_DIAG
+#define R4K_NSTAMP 10
+#define R4K_STAMP(i)                                                                          \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        diag_acc[i] += t_ - diag_prev;                                                        \
+        diag_prev = t_;                                                                       \
+    } while (0)
+#else
+#define R4K_STAMP(i) do { } while (0)
+#endif
 
 // multiply by w16^i (i = 0..3), compile-time i
 template <int I> __device__ __forceinline__ float2 mul_w16(float2 a) {
@@ -134,12 +175,22 @@ __device__ __forceinline__ void exch2_pass3(const float2 (&b0)[16], const float2
 }
 
 // MODE: 0 = peak only, 1 = write |Y|, 2 = write dB
-template <int MODE>
-__global__ void __launch_bounds__(R4K_WAVES * 64)
+// WAVES: waves per (persistent) workgroup = waves per CU.  PF: issue the next frame's 16 loads before the
+// Hermitian post-pass of the current one (needs ~64 more VGPRs, so it pairs with WAVES = 12).
+template <int MODE, int WAVES, bool PF>
+__global__ void __launch_bounds__(WAVES * 64)
 rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __restrict__ win,
                      const float2* __restrict__ twM, const float2* __restrict__ twN, int excl_dc_nyq,
                      float* __restrict__ mag, int32_t* __restrict__ peak_bin, float* __restrict__ peak_mag,
-                     float db_floor) {
+                     float db_floor
+#ifdef R4K_DIAG
+                     , unsigned long long* diag_out
+#endif
+                     ) {
+#ifdef R4K_DIAG
+    unsigned long long diag_acc[R4K_NSTAMP] = {0}, diag_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(diag_prev)::"memory");
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* wtab4 = reinterpret_cast<float4*>(smem_raw);                 // 1024 float4: 0.5 * window
     const int lane = threadIdx.x & 63;
@@ -148,7 +199,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
     float4* slab4 = reinterpret_cast<float4*>(slab);
     float2* slab2 = reinterpret_cast<float2*>(slab);
 
-    for (int i = threadIdx.x; i < 1024; i += R4K_WAVES * 64) {
+    for (int i = threadIdx.x; i < 1024; i += WAVES * 64) {
         float4 w = win ? reinterpret_cast<const float4*>(win)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
         w.x *= 0.5f; w.y *= 0.5f; w.z *= 0.5f; w.w *= 0.5f;
         wtab4[i] = w;
@@ -158,7 +209,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
     // ---- per-lane twiddle bases live in a 3 KiB LDS table (they depend on the lane only), so they
     //      occupy no registers across the frame loop: [0] w_2048^{2t} [1] w_2048^{2t+1} [2] w_128^{t&7}
     //      [3] wA [4] wB [5] wC (Hermitian-pass bases, see below).
-    float2* ctab = reinterpret_cast<float2*>(smem_raw + 4096 * 4 + R4K_WAVES * R4K_SLAB_BYTES);
+    float2* ctab = reinterpret_cast<float2*>(smem_raw + 4096 * 4 + WAVES * R4K_SLAB_BYTES);
     if (threadIdx.x < 64) {
         const int t = threadIdx.x;
         ctab[0 * 64 + t] = twM[2 * t];
@@ -170,12 +221,26 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
     }
     __syncthreads();
 
-    const int64_t nwaves = (int64_t)gridDim.x * R4K_WAVES;
-    for (int64_t frame = (int64_t)blockIdx.x * R4K_WAVES + wave; frame < batch; frame += nwaves) {
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+    const int64_t first = (int64_t)blockIdx.x * WAVES + wave;
+    v4f r[16];
+    // 16 coalesced 1 KiB loads of frame f; past the end the descriptor has zero records, so the
+    // loads are dropped by the range check (returns zeros, touches no memory).
+    auto load_frame = [&](int64_t f) {
+        const bool ok = f < batch;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(x + (ok ? f : 0) * 4096), 0, ok ? 4096 * 4 : 0, 0x00020000);
+        int lx = lane;
+        asm volatile("" : "+v"(lx));
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrs, lx * 16, j * 1024, 0));
+    };
+    for (int64_t frame = first; frame < batch; frame += nwaves) {
         // Buffer descriptors rebuilt per frame from scalars: 32-bit per-lane offsets + immediates keep
         // the address VGPRs at one per access family (no 64-bit per-lane pointers).
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(x + frame * 4096), 0, 4096 * 4, 0x00020000);
+        R4K_STAMP(0);                                   // [0] loop overhead / previous-frame tail
+        if (!PF || frame == first) load_frame(frame);
         // The base twiddles are made opaque once per frame: otherwise LICM hoists every derived power
         // (~140 registers of loop invariants) out of the frame loop and the allocator spills them.
         // Lane-derived addresses are re-derived from an opaque copy of the lane id at the stage that
@@ -185,21 +250,14 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
         const int x1_wr = ln;                                                // float4 index, + 68 * k1'
         const int x1_rd = (ln >> 3) * 136 + (ln & 7);                        // float2 index, + 8 * n2
         float2 va[16], vb[16];
-        {
-            float4 r[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const v4f t4 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrs, ln * 16, j * 1024, 0));
-                r[j] = make_float4(t4[0], t4[1], t4[2], t4[3]);
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float4 w = wtab4[j * 64 + ln];
-                va[j] = mk<float>(r[j].x * w.x, r[j].y * w.y);
-                vb[j] = mk<float>(r[j].z * w.z, r[j].w * w.w);
-            }
+        for (int j = 0; j < 16; ++j) {
+            const float4 w = wtab4[j * 64 + ln];
+            va[j] = mk<float>(r[j][0] * w.x, r[j][1] * w.y);
+            vb[j] = mk<float>(r[j][2] * w.z, r[j][3] * w.w);
         }
         // ---- pass 1: radix-16 over n1 (stride 128), twiddle w_2048^{id k1} ----------------------
+        R4K_STAMP(1);                                   // [1] load issue + wait + window multiply
         stage_fence();
         bfly16<float>(va);
         apply_twiddles16(va, ctab[0 * 64 + ln]);
@@ -209,8 +267,11 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
         stage_fence();
         // ---- exchange 1 + pass 2 (two halves: k1 < 8, k1 >= 8) ----------------------------------
         float2 b0[16], b1[16];
+        R4K_STAMP(2);                                   // [2] pass 1
         exch1_pass2<0>(va, vb, b0, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
+        R4K_STAMP(3);                                   // [3] exchange 1a + pass 2a
         exch1_pass2<1>(va, vb, b1, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
+        R4K_STAMP(4);                                   // [4] exchange 1b + pass 2b
         // ---- exchange 2 + pass 3 (two halves: k2 < 8 -> hl < 128, k2 >= 8 -> hl >= 128) ---------
         int l2 = lane;
         asm volatile("" : "+v"(l2));
@@ -222,8 +283,11 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
         const int hl_p1 = l2, hl_p2 = l2 + 64, hl_q1 = (128 - l2) & 127, hl_q2 = 64 - l2;
         float2 P1[8], P2[8], Q1[8], Q2[8];
         exch2_pass3<0>(b0, b1, P1, P2, slab4, slab2, x2_wr0, x2_wr1, hl_p1, hl_p2);
+        R4K_STAMP(5);                                   // [5] exchange 2a + pass 3a
         exch2_pass3<1>(b0, b1, Q1, Q2, slab4, slab2, x2_wr0, x2_wr1, hl_q1, hl_q2);
+        R4K_STAMP(6);                                   // [6] exchange 2b + pass 3b
         wave_lds_fence();
+        if (PF) { load_frame(frame + nwaves); stage_fence(); }
         // ---- Hermitian post-pass ---------------------------------------------------------------
         // slot 1: (U[i], V[7-i]); generic lanes U = P1, V = Q1; lane 0 owns butterflies 0 and 128.
         int l3 = lane;
@@ -235,6 +299,11 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
         const int kAm = 256 - kA, kBm = special ? 1024 : 256 - l3, kCm = 256 - kC;   // mirrored: 2048 - k = kXm + 256 (7 - i)
         const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
             MODE != 0 ? mag + frame * 2049 : nullptr, 0, MODE != 0 ? 2049 * 4 : 0, 0x00020000);
+        // Spectrum rows are staged in the wave's slab and leave as 16-byte-per-lane stores.  A frame's
+        // row starts 4-byte aligned only (2049 floats per frame), so the row is staged at float offset
+        // o = frame & 3: LDS quad q then maps to the 16-byte ALIGNED global floats 4q - o .. 4q - o + 3.
+        const int o = (int)(frame & 3);
+        float* slabf = reinterpret_cast<float*>(slab);
         unsigned long long key = 0;                     // (|Y| bits << 32) | (4095 - k): max = peak, lowest k
         // emit |Y[kbase + koff]|: kbase is a per-lane register, koff a compile-time constant
         auto emit = [&](float v, int kbase, int koff) {
@@ -242,7 +311,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
             const unsigned long long c = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(4095 - k);
             key = c > key ? c : key;
             if (MODE == 2) v = 20.0f * __log10f(fmaxf(v, db_floor));
-            if (MODE != 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), mrs, kbase * 4, koff * 4, 0);
+            if (MODE != 0) slabf[(kbase + o) + koff] = v;
         };
         const float2 z0 = P1[0];
         {
@@ -296,19 +365,42 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
             emit(v1, 0, 2048);
             if (excl_dc_nyq) key = keep;
         }
-        // ---- dominant peak: wave-wide max of the packed key (np.argmax tie rule: lowest bin) -------
+        if (MODE != 0) {
+            wave_lds_fence();
+            int l4 = lane;
+            asm volatile("" : "+v"(l4));
+            const v4u* slabq = reinterpret_cast<const v4u*>(slab);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned hi = __shfl_xor((unsigned)(key >> 32), off);
-            const unsigned lo = __shfl_xor((unsigned)key, off);
-            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-            key = o > key ? o : key;
+            for (int j = 0; j < 8; ++j) {
+                const int q = l4 + 64 * j;
+                const v4u d = slabq[q];
+                if (j > 0 || l4 > 0)                                 // quad 0 holds the previous row's tail
+                    __builtin_amdgcn_raw_buffer_store_b128(d, mrs, q * 16 - o * 4, 0, 0);
+            }
+            if (l4 < 5) {                                            // 4 - o head floats + o + 1 tail floats
+                const int ke = l4 < 4 - o ? l4 : 2044 + l4;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(slabf[ke + o]), mrs, ke * 4, 0, 0);
+            }
         }
-        if (special) {
-            peak_bin[frame] = 4095 - (int)(unsigned)key;
-            peak_mag[frame] = __uint_as_float((unsigned)(key >> 32));
+        R4K_STAMP(7);                                   // [7] Hermitian post-pass + stores
+        // ---- dominant peak: lane-local best (packed key), then wave max of |Y| and lowest bin among
+        //      the lanes that hold it (np.argmax tie rule) on the DPP path ------------------------------
+        {
+            const float lane_best = __uint_as_float((unsigned)(key >> 32));
+            const unsigned lane_bin = 4095u - (unsigned)key;
+            const float best = wave_max_f32(lane_best);
+            const int bk = wave_min_u32(lane_best == best ? lane_bin : 0x7fffffffu);
+            if (special) {
+                peak_bin[frame] = bk;
+                peak_mag[frame] = best;
+            }
         }
+        R4K_STAMP(8);                                   // [8] peak reduction
     }
+#ifdef R4K_DIAG
+    if (lane == 0)
+        for (int i = 0; i < R4K_NSTAMP; ++i) atomicAdd(&diag_out[i], diag_acc[i]);
+#endif
 }
 
 }  // namespace sa

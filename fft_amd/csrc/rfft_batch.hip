@@ -33,21 +33,35 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     return SA_OK;
 }
 
-template <int MODE>
-static int launch_r4k(const RfftArgs<float>& a, hipStream_t st) {
-    auto kern = rfft4096_wave_kernel<MODE>;
+template <int MODE, int WAVES, bool PF>
+static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st) {
+    auto kern = rfft4096_wave_kernel<MODE, WAVES, PF>;
+    constexpr int lds = r4k_lds_bytes(WAVES);
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R4K_LDS_BYTES));
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    const int64_t need = (a.batch + R4K_WAVES - 1) / R4K_WAVES;
-    const int64_t cap = num_cus();                    // persistent: one 16-wave workgroup per CU
+    const int64_t need = (a.batch + WAVES - 1) / WAVES;
+    const int64_t cap = num_cus();                    // persistent: one workgroup per CU
     const int grid = (int)(need < cap ? need : cap);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(R4K_WAVES * 64), R4K_LDS_BYTES, st, a.x, a.batch, a.win, a.twM, a.twN,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, a.x, a.batch, a.win, a.twM, a.twN,
                        (a.flags & SA_F_EXCLUDE_DC_NYQ) ? 1 : 0, a.mag, a.peak_bin, a.peak_mag, a.db_floor);
     SA_HIP(hipGetLastError());
     return SA_OK;
+}
+
+// SA_R4K_VARIANT (tuning aid): 0 = 16 waves/CU, loads at frame start; 1 = 12 waves/CU with the next
+// frame's loads in flight during the Hermitian post-pass.
+static int r4k_variant() {
+    static const int v = getenv("SA_R4K_VARIANT") ? atoi(getenv("SA_R4K_VARIANT")) : 0;
+    return v;
+}
+
+template <int MODE>
+static int launch_r4k(const RfftArgs<float>& a, hipStream_t st) {
+    if (r4k_variant() == 1) return launch_r4k_v<MODE, 12, true>(a, st);
+    return launch_r4k_v<MODE, 16, false>(a, st);
 }
 
 static bool use_generic_only() {
