@@ -45,3 +45,13 @@ def rfft_peak(x, window="hann", win_param=0.0, write_mag=True, db=False, exclude
     if squeeze:
         return (mag[0] if mag is not None else None), pb[0], pm[0]
     return mag, pb, pm
+
+
+def fft_c2c(x, inverse=False):
+    """Complex fp64 FFT along the last axis (power-of-two length 2..2^30) == scipy.fft.fft / ifft."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.complex128))
+    n = x.shape[-1]
+    batch = x.size // n if n else 0
+    out = np.empty_like(x)
+    _lib.check(_lib.load().sa_fft_c2c_f64(_lib.ptr(x), _lib.ptr(out), n, batch, 1 if inverse else 0))
+    return out

@@ -1,0 +1,331 @@
+// fft_c2c.hip — power-of-two complex-to-complex FFT in fp64 for any length 2 .. 2^30.
+//
+// Serves (i) the GUI drop-in path for frame lengths the batched rfft kernels do not cover
+// (reference main.py:475, 963, 1080: scipy.fft.fft of arbitrary N, through Bluestein in
+// bluestein.hip) and (ii) BASELINE config 5, the single huge fp64 transform.
+//
+//   n <= 4096      one LDS-resident pass;
+//   n <= 2^20      two passes   n = R1 * R2      (each factor 2^6 .. 2^10);
+//   n <= 2^30      three passes n = R1 * R2 * R3.
+// fp64 caps an LDS-resident transform at 8192 points (128 KiB), so 2^30 cannot be done in the two
+// passes a 2^15 x 2^15 split would need: three passes, 3 x (16 B read + 16 B write) per point.
+//
+// Every pass is a decimation-in-frequency step: a strided pass transforms dimension R of the view
+// [A][R][S] (8 adjacent columns per workgroup, 128-byte segments) and multiplies by w_{RS}^{s k}
+// from a two-level table; the last pass transforms contiguous rows and scatters them to natural
+// order with 128-byte coalesced segments.
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "lds_fft.h"
+#include "runtime.h"
+
+namespace sa {
+
+using Cd = double2;
+
+struct C2cArgs {
+    const Cd* in;
+    Cd* out;
+    int64_t n;        // transform length
+    int64_t batch;
+    int64_t A;        // outer count of the [A][R][S] view (strided) / number of rows (final)
+    int64_t S;        // inner stride (strided pass)
+    int64_t R1, R2;   // final pass: row index a = k1 * R2 + k2, natural index = k1 + R1 k2 + R1 R2 k3
+    const Cd* twR;    // w_R^i
+    const Cd* tlo;    // w_Mp^b,        b < 2^h
+    const Cd* thi;    // w_Mp^{a 2^h}
+    int h;
+    int conj_in;      // inverse transform: conjugate on load (first pass)
+    int conj_out;     // inverse transform: conjugate on store (last pass)
+    double scale;     // 1/n for the inverse, else 1
+    int natural;      // final pass: 1 = natural order, 0 = leave digit-reversed
+};
+
+// ---- strided pass ------------------------------------------------------------------------------
+template <int LR, int B>
+__global__ void __launch_bounds__(FftPlan<LR>::TPF * B) c2c_strided_pass(C2cArgs a) {
+    using PL = FftPlan<LR>;
+    constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
+    constexpr int LDSF = lds_fft_elems<double, LR>();
+    constexpr int S = LdsPadShift<double>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Cd* smem = reinterpret_cast<Cd*>(smem_raw);
+    const int col = threadIdx.x % B, tl = threadIdx.x / B;
+    Cd* buf = smem + col * LDSF;
+    const int64_t groups_per_a = a.S / B;
+    const int64_t ngroups = a.batch * a.A * groups_per_a;
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int64_t sg = g % groups_per_a;
+        const int64_t ab = g / groups_per_a;            // = batch * A + a
+        const int64_t s = sg * B + col;
+        const int64_t base = (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + s;
+        Cd v[P];
+#pragma unroll
+        for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; ++n1) {
+                Cd z = a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S];
+                if (a.conj_in) z.y = -z.y;
+                v[u * R0 + n1] = z;
+            }
+        lds_fft<double, LR>(v, buf, tl, a.twR);
+        // twiddle w_{R S}^{s k} and store, B contiguous columns per k
+        constexpr int NT = TPF * B;
+#pragma unroll
+        for (int u = 0; u < (R * B) / NT; ++u) {
+            const int idx = threadIdx.x + NT * u;
+            const int c = idx % B, k = idx / B;
+            Cd z = smem[c * LDSF + lds_pad<S>(k)];
+            const int64_t sc = sg * B + c;
+            const int64_t j = sc * k;                    // < R * S
+            const Cd w = cmul(a.thi[j >> a.h], a.tlo[j & ((1 << a.h) - 1)]);
+            z = cmul(z, w);
+            a.out[(ab / a.A) * a.n + (ab % a.A) * (R * a.S) + (int64_t)k * a.S + sc] = z;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- final (contiguous rows) pass ------------------------------------------------------------------
+template <int LR, int B>
+__global__ void __launch_bounds__(FftPlan<LR>::TPF * B) c2c_final_pass(C2cArgs a) {
+    using PL = FftPlan<LR>;
+    constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
+    constexpr int LDSF = lds_fft_elems<double, LR>();
+    constexpr int S = LdsPadShift<double>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Cd* smem = reinterpret_cast<Cd*>(smem_raw);
+    const int tl = threadIdx.x % TPF, col = threadIdx.x / TPF;
+    Cd* buf = smem + col * LDSF;
+    const int64_t groups_per_t = a.A / B;                // A is a multiple of B (or A == B == 1)
+    const int64_t ngroups = a.batch * groups_per_t;
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int64_t b = g / groups_per_t;
+        const int64_t r0 = (g % groups_per_t) * B;      // first natural-order row index "rev"
+        // row handled by this thread's column: rev = k1 + R1 k2  ->  a = k1 R2 + k2
+        const int64_t rev = r0 + col;
+        const int64_t arow = a.natural ? (rev % a.R1) * a.R2 + rev / a.R1 : rev;
+        const Cd* src = a.in + b * a.n + arow * R;
+        Cd v[P];
+#pragma unroll
+        for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; ++n1) {
+                Cd z = src[n1 * (R / R0) + tl + TPF * u];
+                if (a.conj_in) z.y = -z.y;
+                v[u * R0 + n1] = z;
+            }
+        lds_fft<double, LR>(v, buf, tl, a.twR);
+        constexpr int NT = TPF * B;
+#pragma unroll
+        for (int u = 0; u < (R * B) / NT; ++u) {
+            const int idx = threadIdx.x + NT * u;
+            const int c = idx % B, k = idx / B;
+            Cd z = smem[c * LDSF + lds_pad<S>(k)];
+            z.x *= a.scale; z.y *= a.scale;
+            if (a.conj_out) z.y = -z.y;
+            const int64_t o = a.natural ? (r0 + c) + a.A * (int64_t)k : (r0 + c) * R + k;
+            a.out[b * a.n + o] = z;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+struct TwCtx { int64_t n; int64_t count; int64_t stride; };
+static void fill_tw(void* host, void* ctx) {
+    TwCtx* c = static_cast<TwCtx*>(ctx);
+    std::vector<double> t;
+    host_twiddle(c->n, c->count, c->stride, t);
+    memcpy(host, t.data(), t.size() * sizeof(double));
+}
+static const Cd* tw_table(int64_t n, int64_t count, int64_t stride) {
+    TwCtx c{n, count, stride};
+    const std::string key = "tw64:" + std::to_string(n) + ":" + std::to_string(count) + ":" + std::to_string(stride);
+    return static_cast<const Cd*>(get_cached_table(key, (size_t)count * 16, fill_tw, &c));
+}
+
+template <int LR, int B>
+static int launch_strided(C2cArgs a, hipStream_t st) {
+    constexpr int lds = lds_fft_elems<double, LR>() * B * 16;
+    auto kern = c2c_strided_pass<LR, B>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int64_t ngroups = a.batch * a.A * (a.S / B);
+    const int64_t cap = (int64_t)num_cus() * 16;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR>::TPF * B), lds, st, a);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+template <int LR, int B>
+static int launch_final(C2cArgs a, hipStream_t st) {
+    constexpr int lds = lds_fft_elems<double, LR>() * B * 16;
+    auto kern = c2c_final_pass<LR, B>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int64_t ngroups = a.batch * (a.A / B);
+    const int64_t cap = (int64_t)num_cus() * 16;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR>::TPF * B), lds, st, a);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+static int run_strided(int lr, const C2cArgs& a, hipStream_t st) {
+    switch (lr) {
+        case 6: return launch_strided<6, 8>(a, st);
+        case 7: return launch_strided<7, 8>(a, st);
+        case 8: return launch_strided<8, 8>(a, st);
+        case 9: return launch_strided<9, 8>(a, st);
+        case 10: return launch_strided<10, 8>(a, st);
+    }
+    set_error("c2c: internal factor 2^%d unsupported", lr);
+    return SA_EUNSUP;
+}
+static int run_final_multi(int lr, const C2cArgs& a, hipStream_t st) {
+    switch (lr) {
+        case 6: return launch_final<6, 8>(a, st);
+        case 7: return launch_final<7, 8>(a, st);
+        case 8: return launch_final<8, 8>(a, st);
+        case 9: return launch_final<9, 8>(a, st);
+        case 10: return launch_final<10, 8>(a, st);
+    }
+    set_error("c2c: internal factor 2^%d unsupported", lr);
+    return SA_EUNSUP;
+}
+static int run_final_single(int lr, const C2cArgs& a, hipStream_t st) {
+    switch (lr) {
+        case 1: return launch_final<1, 1>(a, st);
+        case 2: return launch_final<2, 1>(a, st);
+        case 3: return launch_final<3, 1>(a, st);
+        case 4: return launch_final<4, 1>(a, st);
+        case 5: return launch_final<5, 1>(a, st);
+        case 6: return launch_final<6, 1>(a, st);
+        case 7: return launch_final<7, 1>(a, st);
+        case 8: return launch_final<8, 1>(a, st);
+        case 9: return launch_final<9, 1>(a, st);
+        case 10: return launch_final<10, 1>(a, st);
+        case 11: return launch_final<11, 1>(a, st);
+        case 12: return launch_final<12, 1>(a, st);
+    }
+    set_error("c2c: single-pass length 2^%d unsupported", lr);
+    return SA_EUNSUP;
+}
+
+// Fill the two-level twiddle members for a strided pass over a view with Mp = R * S.
+static int set_pass_twiddles(C2cArgs& a, int64_t mp) {
+    int l = 0;
+    while ((1LL << l) < mp) ++l;
+    a.h = (l + 1) / 2;
+    a.tlo = tw_table(mp, 1LL << a.h, 1);
+    a.thi = tw_table(mp, mp >> a.h, 1LL << a.h);
+    return (a.tlo && a.thi) ? SA_OK : SA_EHIP;
+}
+
+int c2c_f64_dev(const double* in, double* out, double* work, int64_t n, int64_t batch, int32_t flags, hipStream_t st) {
+    SA_TRY(ensure_init());
+    int L = 0;
+    while ((1LL << L) < n) ++L;
+    if (n < 2 || (1LL << L) != n || L > 30) { set_error("c2c f64: n=%lld must be a power of two in [2, 2^30]", (long long)n); return SA_EUNSUP; }
+    if (batch <= 0) return batch == 0 ? SA_OK : (set_error("batch < 0"), SA_EINVAL);
+    const bool inverse = flags & 1;
+    C2cArgs a{};
+    a.n = n; a.batch = batch;
+    a.scale = inverse ? 1.0 / (double)n : 1.0;
+    a.natural = (flags & 2) ? 0 : 1;
+    if (L <= 12) {
+        a.in = reinterpret_cast<const Cd*>(in); a.out = reinterpret_cast<Cd*>(out);
+        a.A = 1; a.R1 = 1; a.R2 = 1;
+        a.conj_in = inverse; a.conj_out = inverse;
+        a.twR = tw_table(n, n, 1);
+        if (!a.twR) return SA_EHIP;
+        return run_final_single(L, a, st);
+    }
+    if (!work) { set_error("c2c f64: n > 4096 needs a work buffer of n*batch complex values"); return SA_EINVAL; }
+    int l1, l2, l3 = 0;
+    if (L <= 20) { l1 = (L + 1) / 2; l2 = L - l1; }
+    else { l1 = (L + 2) / 3; l2 = (L - l1 + 1) / 2; l3 = L - l1 - l2; }
+    const int64_t R1 = 1LL << l1, R2 = 1LL << l2, R3 = 1LL << l3;
+    // pass 1: [1][R1][n/R1], in -> work
+    a.in = reinterpret_cast<const Cd*>(in); a.out = reinterpret_cast<Cd*>(work);
+    a.A = 1; a.S = n / R1; a.conj_in = inverse; a.conj_out = 0;
+    a.twR = tw_table(R1, R1, 1);
+    if (!a.twR) return SA_EHIP;
+    SA_TRY(set_pass_twiddles(a, n));
+    SA_TRY(run_strided(l1, a, st));
+    a.conj_in = 0;
+    if (l3 == 0) {
+        // final: rows of R2, A = R1 rows, natural index = k1 + R1 k2
+        a.in = reinterpret_cast<const Cd*>(work); a.out = reinterpret_cast<Cd*>(out);
+        a.A = R1; a.R1 = R1; a.R2 = 1; a.conj_out = inverse;
+        a.twR = tw_table(R2, R2, 1);
+        if (!a.twR) return SA_EHIP;
+        return run_final_multi(l2, a, st);
+    }
+    // pass 2: [R1][R2][R3], work -> work (in place: a workgroup owns its columns)
+    a.in = reinterpret_cast<const Cd*>(work); a.out = reinterpret_cast<Cd*>(work);
+    a.A = R1; a.S = R3;
+    a.twR = tw_table(R2, R2, 1);
+    if (!a.twR) return SA_EHIP;
+    SA_TRY(set_pass_twiddles(a, R2 * R3));
+    SA_TRY(run_strided(l2, a, st));
+    // final: rows of R3, A = R1 R2 rows
+    a.in = reinterpret_cast<const Cd*>(work); a.out = reinterpret_cast<Cd*>(out);
+    a.A = R1 * R2; a.R1 = R1; a.R2 = R2; a.conj_out = inverse;
+    a.twR = tw_table(R3, R3, 1);
+    if (!a.twR) return SA_EHIP;
+    return run_final_multi(l3, a, st);
+}
+
+}  // namespace sa
+
+extern "C" {
+
+int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_t n, int64_t batch, int32_t flags,
+                       void* stream) {
+    SA_TRY(sa::ensure_init());
+    if (!in_ri || !out_ri) { sa::set_error("sa_fft_c2c_f64_dev: NULL buffer"); return SA_EINVAL; }
+    if (flags & ~3) { sa::set_error("sa_fft_c2c_f64_dev: unknown flag bits"); return SA_EINVAL; }
+    hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
+    return sa::c2c_f64_dev(in_ri, out_ri, work, n, batch, flags, st);
+}
+
+int sa_fft_c2c_f64(const double* in_ri, double* out_ri, int64_t n, int64_t batch, int32_t flags) {
+    SA_TRY(sa::ensure_init());
+    if (!in_ri || !out_ri) { sa::set_error("sa_fft_c2c_f64: NULL buffer"); return SA_EINVAL; }
+    if (flags & ~3) { sa::set_error("sa_fft_c2c_f64: unknown flag bits"); return SA_EINVAL; }
+    if (batch <= 0 || n <= 0) { if (batch == 0) return SA_OK; sa::set_error("sa_fft_c2c_f64: bad n/batch"); return SA_EINVAL; }
+    hipStream_t st = sa::thread_stream();
+    const size_t bytes = (size_t)n * batch * 16;
+    double *din = nullptr, *dout = nullptr, *dwork = nullptr;
+    int rc = SA_OK;
+    hipError_t e = hipMalloc(&din, bytes);
+    if (e == hipSuccess) e = hipMalloc(&dout, bytes);
+    if (e == hipSuccess && n > 4096) e = hipMalloc(&dwork, bytes);
+    if (e != hipSuccess) { sa::set_error("sa_fft_c2c_f64: hipMalloc failed: %s", hipGetErrorString(e)); rc = SA_ENOMEM; }
+    if (rc == SA_OK) {
+        e = hipMemcpyAsync(din, in_ri, bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { sa::set_error("H2D copy failed: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+    }
+    if (rc == SA_OK) rc = sa::c2c_f64_dev(din, dout, dwork, n, batch, flags, st);
+    if (rc == SA_OK) {
+        e = hipMemcpyAsync(out_ri, dout, bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { sa::set_error("D2H copy failed: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+    }
+    if (din) hipFree(din);
+    if (dout) hipFree(dout);
+    if (dwork) hipFree(dwork);
+    return rc;
+}
+
+}  // extern "C"

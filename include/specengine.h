@@ -104,6 +104,19 @@ int sa_time_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t 
  * Same formula is restated on the host in oracle/ for parity tests. */
 int sa_fill_tone_noise_f32_dev(float* x, int64_t batch, int32_t n, double fs, uint64_t seed, void* stream);
 
+/* ---- a6 for lengths outside the batched rfft kernels, and BASELINE config 5 --------------------
+ * Complex-to-complex fp64 FFT, interleaved (re, im), unnormalised forward e^{-2 pi i k n/N}
+ * (scipy.fft.fft, main.py:475); flags bit0 = inverse (conjugate transform scaled by 1/n, scipy.fft.ifft),
+ * bit1 = leave the output in digit-reversed order (skips the final scatter; n > 4096 only).
+ * n: power of two, 2 <= n <= 2^30.  1 pass in LDS for n <= 4096, 2 passes to 2^20, 3 passes to 2^30.
+ * `work` (device variant): scratch of n*batch complex values, may be NULL when n <= 4096; in/out may alias
+ * only when n <= 4096. */
+#define SA_FFT_INVERSE        1
+#define SA_FFT_DIGITREV_OUT   2
+int sa_fft_c2c_f64(const double* in_ri, double* out_ri, int64_t n, int64_t batch, int32_t flags);
+int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_t n, int64_t batch,
+                       int32_t flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
