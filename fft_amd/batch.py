@@ -55,3 +55,25 @@ def fft_c2c(x, inverse=False):
     out = np.empty_like(x)
     _lib.check(_lib.load().sa_fft_c2c_f64(_lib.ptr(x), _lib.ptr(out), n, batch, 1 if inverse else 0))
     return out
+
+
+def fft_mag(x, window="none", win_param=0.0, write_mag=True, db=False, exclude_dc_nyq=False):
+    """|fft(x*w)| bins 0..n/2 + dominant peak for real fp64 frames of ANY length (x: [batch, n] or [n])."""
+    x = np.asarray(x, dtype=np.float64)
+    squeeze = x.ndim == 1
+    if squeeze:
+        x = x[None, :]
+    if x.ndim != 2:
+        raise ValueError("x must be [batch, n] or [n]")
+    x = np.ascontiguousarray(x)
+    batch, n = x.shape
+    flags = (_lib.F_WRITE_MAG if write_mag else 0) | (_lib.F_DB if db else 0) | \
+            (_lib.F_EXCLUDE_DC_NYQ if exclude_dc_nyq else 0)
+    mag = np.empty((batch, n // 2 + 1), dtype=np.float64) if write_mag else None
+    pb = np.empty(batch, dtype=np.int32)
+    pm = np.empty(batch, dtype=np.float64)
+    _lib.check(_lib.load().sa_fft_mag_f64(_lib.ptr(x), batch, n, window_id(window), float(win_param), flags,
+                                          _lib.ptr(mag), _lib.ptr(pb), _lib.ptr(pm)))
+    if squeeze:
+        return (mag[0] if mag is not None else None), pb[0], pm[0]
+    return mag, pb, pm

@@ -156,6 +156,9 @@ int rfft_peak_dev(const T* x, int64_t batch, int32_t n, int32_t window, double w
     return dispatch_generic<T>(log2n, a, st);
 }
 
+template int rfft_peak_dev<double>(const double*, int64_t, int32_t, int32_t, double, int32_t, double*, int32_t*, double*, hipStream_t);
+template int rfft_peak_dev<float>(const float*, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);
+
 // Host-pointer variant: stage through device memory in chunks, synchronise before returning.
 template <typename T>
 int rfft_peak_host(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,

@@ -117,6 +117,16 @@ int sa_fft_c2c_f64(const double* in_ri, double* out_ri, int64_t n, int64_t batch
 int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_t n, int64_t batch,
                        int32_t flags, void* stream);
 
+/* ---- a6/a8/a9 for ARBITRARY frame length (the GUI drop-in path) ----------------------------------
+ * |fft(y*w)| of real fp64 frames of any length n >= 1: bins 0..n/2, plus the dominant peak.
+ * Replaces scipy.fft.fft + np.abs + np.argmax for the N the GUI produces: int(duration*Fs), e.g. 2000
+ * (main.py:105-107, 475, 511), the 1500-sample FNIRSI import (main.py:1080) and any len(y) handed to
+ * _calculate_fft (main.py:959-965).  Power-of-two n run on the rfft / c2c kernels, every other n
+ * through Bluestein's chirp-z on the c2c engine (fp64, chirp phases exact via k^2 mod 2n).
+ *   x [batch][n], mag [batch][n/2+1], peak_bin/peak_mag [batch]; same window ids and flags as above. */
+int sa_fft_mag_f64(const double* x, int64_t batch, int64_t n, int32_t window, double win_param,
+                   int32_t flags, double* mag, int32_t* peak_bin, double* peak_mag);
+
 #ifdef __cplusplus
 }
 #endif
