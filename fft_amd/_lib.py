@@ -45,7 +45,16 @@ PROTOTYPES = {
     "sa_fft_c2c_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i32]),
     "sa_fft_c2c_f64_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "sa_fft_mag_f64": (C.c_int, [_vp, _i64, _i64, _i32, _dbl, _i32, _vp, _vp, _vp]),
+    "sa_synth_f64": (C.c_int, [_vp, _vp, _vp]),
+    "sa_compute_f64": (C.c_int, [_vp, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+class GenParams(C.Structure):
+    """struct sa_gen_params (include/specengine.h)."""
+    _fields_ = [("waveform", _i32), ("am_on", _i32), ("fm_on", _i32), ("apply_vpp", _i32), ("N", _i64),
+                ("duration", _dbl), ("Fc", _dbl), ("Fs", _dbl), ("Fm", _dbl), ("am_depth", _dbl),
+                ("fm_dev", _dbl), ("vpp_half", _dbl), ("seed", _u64)]
 
 
 def load():

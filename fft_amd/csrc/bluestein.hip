@@ -163,7 +163,7 @@ static int ilog2e(int64_t n) {
 }
 
 // Device-side worker on `cnt` frames already resident in dx; writes dmag/dpb/dpm (device).
-static int fft_mag_any_dev(const double* dx, int64_t cnt, int64_t n, int window, double win_param, int flags, double* dmag,
+int fft_mag_any_dev(const double* dx, int64_t cnt, int64_t n, int window, double win_param, int flags, double* dmag,
                            int32_t* dpb, double* dpm, hipStream_t st) {
     const int64_t nb = n / 2 + 1;
     const int l2 = ilog2e(n);

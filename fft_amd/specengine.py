@@ -1,0 +1,167 @@
+"""specengine — drop-in replacement for the numeric core of the Gecesars/FFT analyzer.
+
+Mirrors, name for name and argument for argument, what the reference GUI computes inline:
+
+    validate_inputs(...)          == SignalGeneratorApp._validate_inputs        (main.py:490-534)
+    compute(p, vpp)               == _compute_and_plot_task's numeric body      (main.py:460-479)
+                                     -> the `last_data` dict {'t','y','f','Y'}
+    calculate_fft(t, y)           == SignalGeneratorApp._calculate_fft          (main.py:959-965)
+    dominant_peak(f, Y, positive_only) == np.argmax read-outs                   (main.py:1029-1031, 1622-1629)
+
+Everything numeric runs on the GPU through libspecengine.so (ctypes, include/specengine.h): waveform
+synthesis + AM/FM (sa_compute_f64 / sa_synth_f64) and the fp64 |FFT| of arbitrary length
+(sa_fft_mag_f64).  The device returns the n/2+1 real-FFT bins; this module rebuilds the reference's
+layout on the host: length-N arrays in fftshift order, with |Y| mirrored by Hermitian symmetry
+(exactly symmetric, like scipy.fft.fft on real input, so np.argmax lands on the same negative-
+frequency twin as in the reference).  There is no CPU fallback.
+"""
+import logging
+
+import numpy as np
+
+from . import _lib
+
+log = logging.getLogger("specengine")
+
+UNIT_MULTIPLIERS = {"Hz": 1, "kHz": 1e3, "MHz": 1e6, "GHz": 1e9}     # main.py:28
+
+# Portuguese GUI labels (main.py:540-612) -> enum sa_waveform
+WAVEFORMS = ["Seno", "Cosseno", "Quadrada", "Triangular", "Dente de Serra", "Pulso", "Ruído Branco",
+             "Exp Decaimento", "Passo (step)", "Rampa", "Parábola", "Impulso", "Tangente", "Sinc", "Gaussiana",
+             "Chirp Linear", "Chirp Quadrático", "Onda AM", "Onda FM", "Batimento", "Lorentziana", "Hiperbólica",
+             "Bessel", "Sinc Modulado", "Pulso Gaussiano", "Dente de Serra Modificado", "Onda AM-DSB",
+             "Onda FM Estéreo", "Onda Quadrada Modulada", "Onda Triangular Modulada", "Pulso Exponencial",
+             "Onda Comb", "Onda Harmônica"]
+WAVEFORM_IDS = {name: i for i, name in enumerate(WAVEFORMS)}
+WF_UNKNOWN = 255
+
+
+def validate_inputs(duration, Fc, Fs, Fm, waveform, am_on=False, am_depth=0.5, fm_on=False, fm_dev=50.0):
+    """Same checks, same messages, same dict as main.py:492-529 (raises ValueError; the GUI shows it)."""
+    p = {"duration": float(duration), "Fc": float(Fc), "Fs": float(Fs), "Fm": float(Fm), "waveform": waveform,
+         "am_on": am_on, "am_depth": am_depth, "fm_on": fm_on, "fm_dev": fm_dev}
+    if p["duration"] <= 0:
+        raise ValueError("Duração deve ser maior que zero.")
+    if p["Fs"] <= 0:
+        raise ValueError("Taxa de amostragem deve ser maior que zero.")
+    p["N"] = int(p["duration"] * p["Fs"])
+    if p["N"] < 16:
+        raise ValueError("Combinação de duração e Fs resulta em poucos pontos (< 16).")
+    if p["N"] % 2 != 0:
+        p["N"] += 1
+    max_freq = max(p["Fc"], p["Fm"])
+    if max_freq >= p["Fs"] / 2:
+        raise ValueError(f"Nyquist violado! Máxima frequência ({max_freq}Hz) deve ser < Fs/2 ({p['Fs'] / 2}Hz).")
+    return p
+
+
+# ---- host-side layout helpers (pure numpy, unit-tested on CPU) ------------------------------------
+def shifted_freq_axis(n, fs):
+    """fftshift(fftfreq(n, 1/fs)) (main.py:476, 964), same arithmetic as scipy: k / (n * d) with d = 1/fs."""
+    d = 1 / fs
+    k = np.arange(-(n // 2), (n + 1) // 2, dtype=np.int64)
+    return k * (1.0 / (n * d))
+
+
+def mirror_half_to_shifted(mag_half, n):
+    """Bins 0..n//2 of a real signal's spectrum -> length-n |Y| in fftshift order (main.py:475, 479).
+
+    Shifted index i holds bin j = i - n//2; |Y[j]| = |Y[-j]| (Hermitian), so Yabs[i] = mag_half[|j|]."""
+    mag_half = np.asarray(mag_half)
+    if mag_half.shape[-1] != n // 2 + 1:
+        raise ValueError("mag_half must have n//2+1 bins")
+    j = np.abs(np.arange(-(n // 2), (n + 1) // 2))
+    return np.ascontiguousarray(mag_half[..., j])
+
+
+def shifted_index_of_bin(k, n):
+    """Index into the fftshift-ordered array where np.argmax finds rfft bin k first (negative twin)."""
+    return n // 2 - k
+
+
+def _gen_params(p, vpp):
+    gp = _lib.GenParams()
+    gp.waveform = WAVEFORM_IDS.get(p["waveform"], WF_UNKNOWN)
+    gp.am_on = 1 if p.get("am_on") else 0
+    gp.fm_on = 1 if p.get("fm_on") else 0
+    gp.apply_vpp = 0 if vpp is None else 1
+    gp.N = int(p["N"])
+    gp.duration = float(p["duration"])
+    gp.Fc, gp.Fs, gp.Fm = float(p["Fc"]), float(p["Fs"]), float(p["Fm"])
+    gp.am_depth = float(p.get("am_depth", 0.0))
+    gp.fm_dev = float(p.get("fm_dev", 0.0))
+    gp.vpp_half = 0.0 if vpp is None else float(vpp) / 2
+    gp.seed = int(p.get("seed", np.random.SeedSequence().entropy & 0xFFFFFFFFFFFFFFFF))
+    return gp
+
+
+def generate(p, vpp=None):
+    """(t, y) of main.py:460-472: synthesis, amplitude, AM/FM — on the GPU."""
+    import ctypes as C
+    gp = _gen_params(p, vpp)
+    n = gp.N
+    t = np.empty(n, dtype=np.float64)
+    y = np.empty(n, dtype=np.float64)
+    _lib.check(_lib.load().sa_synth_f64(C.byref(gp), _lib.ptr(t), _lib.ptr(y)))
+    return t, y
+
+
+def compute(p, vpp=None, window="none", win_param=0.0):
+    """main.py:460-479 -> {'t','y','f','Y'} (all float64 ndarrays of length N, f/Y in fftshift order).
+
+    `vpp=None` reproduces the reference's fallback when the Vpp entry does not parse (main.py:467-468).
+    `window` is an extension (the reference applies none); the default keeps parity."""
+    import ctypes as C
+    from .batch import window_id
+    gp = _gen_params(p, vpp)
+    n = gp.N
+    t = np.empty(n, dtype=np.float64)
+    y = np.empty(n, dtype=np.float64)
+    mag = np.empty(n // 2 + 1, dtype=np.float64)
+    pb = np.empty(1, dtype=np.int32)
+    pm = np.empty(1, dtype=np.float64)
+    _lib.check(_lib.load().sa_compute_f64(C.byref(gp), window_id(window), float(win_param), 0, _lib.ptr(t),
+                                          _lib.ptr(y), _lib.ptr(mag), _lib.ptr(pb), _lib.ptr(pm)))
+    f = shifted_freq_axis(n, p["Fs"])
+    log.debug("compute: N=%d waveform=%s peak bin %d", n, p["waveform"], int(pb[0]))
+    return {"t": t, "y": y, "f": f, "Y": mirror_half_to_shifted(mag, n)}
+
+
+def calculate_fft(t, y):
+    """_calculate_fft(t, y) -> (f, |Y|), both length N in fftshift order (main.py:959-965).
+
+    Accepts lists or arrays of any length (main.py:1071-1084 passes a python list of 1500 floats);
+    Fs is estimated as 1/(t[1]-t[0]) exactly like the reference."""
+    from .batch import fft_mag
+    y = np.asarray(y, dtype=np.float64)
+    if y.ndim != 1:
+        raise ValueError("y must be one-dimensional")
+    n = len(y)
+    fs = 1 / (t[1] - t[0]) if len(t) > 1 else 1
+    mag, _, _ = fft_mag(y, "none")
+    return shifted_freq_axis(n, fs), mirror_half_to_shifted(mag, n)
+
+
+def dominant_peak(f, Y, positive_only=False):
+    """(index, frequency, amplitude) as the reference reads them:
+    positive_only=False: np.argmax on the full shifted array (main.py:1029-1031, 1318-1319);
+    positive_only=True : np.argmax after the f > 0 mask (main.py:1622-1629).
+    Host-side read-out of arrays the device produced (O(N) scan of data already on the host)."""
+    f = np.asarray(f)
+    Y = np.asarray(Y)
+    if positive_only:
+        m = f > 0
+        fp, Yp = f[m], Y[m]
+        i = int(np.argmax(Yp))
+        return i, float(fp[i]), float(Yp[i])
+    i = int(np.argmax(Y))
+    return i, float(f[i]), float(Y[i])
+
+
+def analyze(y, fs, window="none", win_param=0.0, exclude_dc_nyq=True):
+    """Device-side peak of one frame: (bin k, frequency k*fs/n, |Y[k]|) over rfft bins — the GPU
+    counterpart of dominant_peak(positive_only=True) without materialising the spectrum on the host."""
+    from .batch import fft_mag
+    y = np.asarray(y, dtype=np.float64)
+    _, pb, pm = fft_mag(y, window, win_param, write_mag=False, exclude_dc_nyq=exclude_dc_nyq)
+    return int(pb), float(pb) * fs / len(y), float(pm)

@@ -127,6 +127,43 @@ int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_
 int sa_fft_mag_f64(const double* x, int64_t batch, int64_t n, int32_t window, double win_param,
                    int32_t flags, double* mag, int32_t* peak_bin, double* peak_mag);
 
+/* ---- a2/a3/a4/a5: waveform synthesis + AM/FM on the device, fp64 -----------------------------------
+ * One enum value per branch of _generate_waveform (main.py:536-615), in source order; anything else
+ * yields zeros like the reference's final else (main.py:614-615). */
+enum sa_waveform {
+    SA_WF_SENO = 0, SA_WF_COSSENO, SA_WF_QUADRADA, SA_WF_TRIANGULAR, SA_WF_DENTE_DE_SERRA, SA_WF_PULSO,
+    SA_WF_RUIDO_BRANCO, SA_WF_EXP_DECAIMENTO, SA_WF_PASSO, SA_WF_RAMPA, SA_WF_PARABOLA, SA_WF_IMPULSO,
+    SA_WF_TANGENTE, SA_WF_SINC, SA_WF_GAUSSIANA, SA_WF_CHIRP_LINEAR, SA_WF_CHIRP_QUADRATICO, SA_WF_ONDA_AM,
+    SA_WF_ONDA_FM, SA_WF_BATIMENTO, SA_WF_LORENTZIANA, SA_WF_HIPERBOLICA, SA_WF_BESSEL, SA_WF_SINC_MODULADO,
+    SA_WF_PULSO_GAUSSIANO, SA_WF_DENTE_DE_SERRA_MOD, SA_WF_ONDA_AM_DSB, SA_WF_ONDA_FM_ESTEREO,
+    SA_WF_QUADRADA_MODULADA, SA_WF_TRIANGULAR_MODULADA, SA_WF_PULSO_EXPONENCIAL, SA_WF_ONDA_COMB,
+    SA_WF_ONDA_HARMONICA, SA_WF_UNKNOWN = 255
+};
+
+/* The dict `p` of _validate_inputs (main.py:492-502, 511) plus the amplitude of main.py:464-468. */
+typedef struct sa_gen_params {
+    int32_t  waveform;     /* enum sa_waveform                                            */
+    int32_t  am_on;        /* p['am_on']                                                  */
+    int32_t  fm_on;        /* p['fm_on']                                                  */
+    int32_t  apply_vpp;    /* 0 mirrors the reference's "invalid Vpp entry" path (:467)   */
+    int64_t  N;            /* p['N'] (even, >= 16 when it comes from _validate_inputs)    */
+    double   duration;     /* p['duration'] seconds                                       */
+    double   Fc, Fs, Fm;   /* Hz                                                          */
+    double   am_depth;     /* p['am_depth']                                               */
+    double   fm_dev;       /* p['fm_dev'] Hz                                              */
+    double   vpp_half;     /* vpp / 2                                                     */
+    uint64_t seed;         /* white-noise stream (reference: unseeded np.random.normal)   */
+} sa_gen_params;
+
+/* y = _apply_modulation(p, _generate_waveform(p, t) * vpp/2, t), t = arange(N)/Fs  (main.py:460-472).
+ * t_out may be NULL. Host buffers of N doubles. */
+int sa_synth_f64(const sa_gen_params* p, double* t_out, double* y_out);
+
+/* The whole of main.py:460-479 in one call: synthesis -> modulation -> |fft(y*w)| (bins 0..N/2) -> peak.
+ * window SA_WIN_NONE reproduces the reference (which applies no window). y_out[N], mag[N/2+1]. */
+int sa_compute_f64(const sa_gen_params* p, int32_t window, double win_param, int32_t flags, double* t_out,
+                   double* y_out, double* mag, int32_t* peak_bin, double* peak_mag);
+
 #ifdef __cplusplus
 }
 #endif

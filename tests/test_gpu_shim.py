@@ -1,0 +1,112 @@
+"""GPU parity of the drop-in shim against vectors captured from the reference's own methods."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from fft_amd import specengine as S
+
+pytestmark = pytest.mark.gpu
+
+DISCONTINUOUS = {"Quadrada", "Pulso", "Onda Quadrada Modulada", "Onda Comb", "Passo (step)", "Impulso"}
+
+
+def test_compute_matches_reference_last_data(golden_dir):
+    """All 5 parameter sets x 33 waveform names of main.py:536-615 (+ AM / FM / AM+FM modulation)."""
+    z = np.load(os.path.join(golden_dir, "ref_compute.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "ref_compute.json"), encoding="utf-8"))
+    worst = 0.0
+    for case in meta["cases"]:
+        key, p, vpp = case["key"], case["p"], case["vpp"]
+        y_ref, Y_ref = z[key + "_y"], z[key + "_Y"]
+        out = S.compute(p, vpp)
+        ci = key.split("_")[0]
+        assert set(out) == {"t", "y", "f", "Y"} and all(isinstance(v, np.ndarray) and v.dtype == np.float64 and len(v) == p["N"] for v in out.values())
+        np.testing.assert_array_equal(out["t"], z[ci + "_t"])
+        np.testing.assert_array_equal(out["f"], z[ci + "_f"])
+        wf = p["waveform"]
+        if not np.isfinite(y_ref).all():                 # Rampa/Parábola never hit this; guard only
+            continue
+        scale = max(1.0, np.abs(y_ref).max())
+        if wf == "Hiperbólica":                          # sinh(2 pi Fc t) overflows to 1e300+: relative compare
+            np.testing.assert_allclose(out["y"], y_ref, rtol=1e-9, err_msg=key)
+            continue
+        tol = 1e-12 * scale
+        if p["fm_on"] and not wf.startswith("Onda"):
+            tol = 1e-10                                   # blocked prefix sum vs numpy's sequential cumsum
+        if wf.startswith("Chirp"):
+            tol = 2e-11                                   # phase reaches ~1e4 rad: 1 ulp of phase (t**3 via pow in numpy) ~ 2e-12
+        if wf in DISCONTINUOUS or wf in ("Triangular", "Dente de Serra", "Dente de Serra Modificado", "Onda Triangular Modulada"):
+            # same sample-exact edges as numpy (phase and fmod are evaluated in numpy's order)
+            if not p["fm_on"]:
+                assert np.abs(out["y"] - y_ref).max() <= tol, (key, wf)
+        else:
+            assert np.abs(out["y"] - y_ref).max() <= tol, (key, wf, np.abs(out["y"] - y_ref).max())
+        err = np.abs(out["Y"] - Y_ref).max() / max(Y_ref.max(), 1e-300)
+        if np.abs(out["y"] - y_ref).max() <= tol:
+            assert err < max(1e-12, 50 * tol), (key, wf, err)
+            worst = max(worst, err)
+        np.testing.assert_array_equal(out["Y"][1:], out["Y"][1:][::-1])      # exact Hermitian mirror (even N)
+    assert worst < 1e-10
+
+
+def test_config1_through_the_shim(golden_dir):
+    """BASELINE config 1: same read-outs as the reference GUI (index 1638, f = -10009.765..., 1549.17...)."""
+    kat = json.load(open(os.path.join(golden_dir, "config1_kat.json")))
+    p = S.validate_inputs(0.04096, 10e3, 100e3, 10.0, "Seno")
+    assert p["N"] == 4096
+    out = S.compute(p, 2.0)
+    i, fr, amp = S.dominant_peak(out["f"], out["Y"])
+    assert i == kat["argmax_shifted"] == 1638
+    assert fr == kat["f_at_argmax"]
+    assert amp == pytest.approx(kat["max_abs"], rel=1e-12)
+    i2, f2, a2 = S.dominant_peak(out["f"], out["Y"], positive_only=True)
+    assert f2 == -fr and a2 == amp
+    hw = S.compute(p, 2.0, window="hamming")
+    k = 4096 // 2 - int(np.argmax(hw["Y"]))
+    assert k == kat["hamming_rfft_argmax"] == 410
+    assert hw["Y"].max() == pytest.approx(kat["hamming_rfft_max"], rel=1e-12)
+    k3, f3, a3 = S.analyze(out["y"], p["Fs"], "hamming")
+    assert k3 == 410 and f3 == pytest.approx(kat["hamming_rfft_freq"], rel=1e-15)
+
+
+def test_calculate_fft_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "ref_calculate_fft.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "ref_calculate_fft.json")))
+    for case in meta["cases"]:
+        n = case["N"]
+        f, Y = S.calculate_fft(z[f"n{n}_t"], z[f"n{n}_y"])
+        np.testing.assert_array_equal(f, z[f"n{n}_f"])
+        assert Y.dtype == np.float64 and len(Y) == n
+        assert np.abs(Y - z[f"n{n}_Y"]).max() / z[f"n{n}_Y"].max() < 1e-12
+        i, fr, amp = S.dominant_peak(f, Y)
+        # exact mirror -> np.argmax picks the same (negative-frequency) twin as in the reference
+        assert i == case["argmax_full"] and fr == case["f_full"]
+        if "argmax_pos" in case:
+            assert S.dominant_peak(f, Y, positive_only=True)[0] == case["argmax_pos"]
+    # FNIRSI import path: python list of 1500 floats (main.py:1071-1084)
+    f, Y = S.calculate_fft(z["fnirsi_t"], list(z["fnirsi_y"]))
+    np.testing.assert_array_equal(f, z["fnirsi_f"])
+    assert np.abs(Y - z["fnirsi_Y"]).max() / z["fnirsi_Y"].max() < 1e-12
+
+
+def test_white_noise_statistics():
+    p = S.validate_inputs(1.0, 1e3, 2e5, 10.0, "Ruído Branco")
+    p["seed"] = 1234
+    t, y = S.generate(p, 2.0)
+    assert abs(y.mean()) < 0.01 and abs(y.std() - 0.5) < 0.01           # np.random.normal(0, 0.5, N), main.py:553
+    from scipy import stats
+    assert abs(stats.kurtosis(y)) < 0.1 and abs(stats.skew(y)) < 0.05
+    assert abs(np.corrcoef(y[:-1], y[1:])[0, 1]) < 0.01
+    p["seed"] = 1235
+    assert not np.array_equal(S.generate(p, 2.0)[1], y)
+
+
+def test_export_contract():
+    """export_data does v.tolist() and zip(*last_data.values()) (main.py:1776-1781): equal-length ndarrays."""
+    p = S.validate_inputs(0.1, 1000.0, 20000.0, 100.0, "Triangular")
+    d = S.compute(p, 3.0)
+    rows = list(zip(*d.values()))
+    assert len(rows) == 2000 and len(rows[0]) == 4
+    json.dumps({k: v.tolist() for k, v in d.items()})
