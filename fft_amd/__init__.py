@@ -5,6 +5,6 @@ Host side is a thin ctypes layer over fft_amd/libspecengine.so (C ABI: include/s
 dominant_peak, reference main.py:452-479, 959-965, 1029, 1622-1629).
 """
 from . import _lib  # noqa: F401
-from .batch import fft_c2c, fft_mag, rfft_peak, window_id  # noqa: F401
+from .batch import fft_c2c, fft_mag, rfft_peak, stft_pcm16, window_id  # noqa: F401
 
-__all__ = ["rfft_peak", "fft_c2c", "fft_mag", "window_id"]
+__all__ = ["rfft_peak", "fft_c2c", "fft_mag", "stft_pcm16", "window_id"]

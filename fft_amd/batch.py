@@ -77,3 +77,28 @@ def fft_mag(x, window="none", win_param=0.0, write_mag=True, db=False, exclude_d
     if squeeze:
         return (mag[0] if mag is not None else None), pb[0], pm[0]
     return mag, pb, pm
+
+
+def stft_pcm16(pcm, nfft=8192, hop=2048, window="blackman", win_param=0.0, write_mag=True, db=False,
+               exclude_dc_nyq=False):
+    """Short-time |FFT| + per-frame peak of PCM16 audio. pcm: int16 [n_samples, channels] (or [n_samples]).
+
+    Returns (mag float32 [channels, frames, nfft/2+1] or None, peak_bin int32 [channels, frames],
+    peak_mag float32 [channels, frames]); frames = (n_samples - nfft)//hop + 1 (no padding)."""
+    pcm = np.asarray(pcm)
+    if pcm.dtype != np.int16:
+        raise ValueError("pcm must be int16")
+    if pcm.ndim == 1:
+        pcm = pcm[:, None]
+    pcm = np.ascontiguousarray(pcm)
+    ns, ch = pcm.shape
+    lib = _lib.load()
+    nf = int(lib.sa_stft_num_frames(ns, nfft, hop))
+    flags = (_lib.F_WRITE_MAG if write_mag else 0) | (_lib.F_DB if db else 0) | \
+            (_lib.F_EXCLUDE_DC_NYQ if exclude_dc_nyq else 0)
+    mag = np.empty((ch, nf, nfft // 2 + 1), dtype=np.float32) if write_mag else None
+    pb = np.empty((ch, nf), dtype=np.int32)
+    pm = np.empty((ch, nf), dtype=np.float32)
+    _lib.check(lib.sa_stft_pcm16(_lib.ptr(pcm), ns, ch, nfft, hop, window_id(window), float(win_param), flags,
+                                 _lib.ptr(mag), _lib.ptr(pb), _lib.ptr(pm)))
+    return mag, pb, pm

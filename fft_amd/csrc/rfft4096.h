@@ -179,7 +179,7 @@ __device__ __forceinline__ void exch2_pass3(const float2 (&b0)[16], const float2
 // Hermitian post-pass of the current one (needs ~64 more VGPRs, so it pairs with WAVES = 12).
 template <int MODE, int WAVES, bool PF>
 __global__ void __launch_bounds__(WAVES * 64)
-rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __restrict__ win,
+rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_stride, const float* __restrict__ win,
                      const float2* __restrict__ twM, const float2* __restrict__ twN, int excl_dc_nyq,
                      float* __restrict__ mag, int32_t* __restrict__ peak_bin, float* __restrict__ peak_mag,
                      float db_floor
@@ -229,7 +229,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, const float* __
     auto load_frame = [&](int64_t f) {
         const bool ok = f < batch;
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(x + (ok ? f : 0) * 4096), 0, ok ? 4096 * 4 : 0, 0x00020000);
+            const_cast<float*>(x + (ok ? f : 0) * frame_stride), 0, ok ? 4096 * 4 : 0, 0x00020000);
         int lx = lane;
         asm volatile("" : "+v"(lx));
 #pragma unroll

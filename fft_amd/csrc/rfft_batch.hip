@@ -45,7 +45,7 @@ static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st) {
     const int64_t need = (a.batch + WAVES - 1) / WAVES;
     const int64_t cap = num_cus();                    // persistent: one workgroup per CU
     const int grid = (int)(need < cap ? need : cap);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, a.x, a.batch, a.win, a.twM, a.twN,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, a.x, a.batch, a.frame_stride, a.win, a.twM, a.twN,
                        (a.flags & SA_F_EXCLUDE_DC_NYQ) ? 1 : 0, a.mag, a.peak_bin, a.peak_mag, a.db_floor);
     SA_HIP(hipGetLastError());
     return SA_OK;
@@ -74,7 +74,7 @@ static int dispatch_generic(int log2n, const RfftArgs<T>& a, hipStream_t st);
 
 template <>
 int dispatch_generic<float>(int log2n, const RfftArgs<float>& a, hipStream_t st) {
-    if (log2n == 12 && !use_generic_only()) {
+    if (log2n == 12 && !use_generic_only() && (a.frame_stride % 4) == 0) {
         const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
         if (!wmag) return launch_r4k<0>(a, st);
         return (a.flags & SA_F_DB) ? launch_r4k<2>(a, st) : launch_r4k<1>(a, st);
@@ -138,8 +138,8 @@ static int check_args(const T* x, int64_t batch, int32_t n, int32_t window, int3
 }
 
 template <typename T>
-int rfft_peak_dev(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
-                  T* mag, int32_t* peak_bin, T* peak_mag, hipStream_t st) {
+int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32_t n, int32_t window, double win_param,
+                          int32_t flags, T* mag, int32_t* peak_bin, T* peak_mag, hipStream_t st) {
     SA_TRY(ensure_init());
     int log2n = 0;
     SA_TRY(check_args(x, batch, n, window, flags, mag, peak_bin, peak_mag, &log2n));
@@ -147,7 +147,7 @@ int rfft_peak_dev(const T* x, int64_t batch, int32_t n, int32_t window, double w
     const RfftPlan* p = get_rfft_plan(sizeof(T) == 8, n, window, win_param);
     if (!p) return SA_EHIP;
     RfftArgs<T> a;
-    a.x = x; a.batch = batch;
+    a.x = x; a.batch = batch; a.frame_stride = frame_stride > 0 ? frame_stride : n;
     a.win = static_cast<const T*>(p->d_win);
     a.twM = static_cast<const cplx<T>*>(p->d_twM);
     a.twN = static_cast<const cplx<T>*>(p->d_twN);
@@ -156,6 +156,12 @@ int rfft_peak_dev(const T* x, int64_t batch, int32_t n, int32_t window, double w
     return dispatch_generic<T>(log2n, a, st);
 }
 
+template <typename T>
+int rfft_peak_dev(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
+                  T* mag, int32_t* peak_bin, T* peak_mag, hipStream_t st) {
+    return rfft_peak_strided_dev<T>(x, batch, n, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
+}
+template int rfft_peak_strided_dev<float>(const float*, int64_t, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);
 template int rfft_peak_dev<double>(const double*, int64_t, int32_t, int32_t, double, int32_t, double*, int32_t*, double*, hipStream_t);
 template int rfft_peak_dev<float>(const float*, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);
 

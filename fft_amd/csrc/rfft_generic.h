@@ -33,8 +33,9 @@ template <typename T> __device__ __forceinline__ bool peak_better(T m, int k, T 
 
 // Kernel parameters
 template <typename T> struct RfftArgs {
-    const T* x;            // [batch][n]
+    const T* x;            // frame b starts at x + b * frame_stride
     int64_t batch;
+    int64_t frame_stride;  // n for packed frames, hop for overlapping (STFT) frames
     const T* win;          // [n] or nullptr (SA_WIN_NONE)
     const cplx<T>* twM;    // [M]      w_M^i
     const cplx<T>* twN;    // [M/2+1]  w_N^i
@@ -69,7 +70,7 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
     for (int64_t base = (int64_t)blockIdx.x * FPW; base < a.batch; base += (int64_t)gridDim.x * FPW) {
         const int64_t frame = base + g;
         const bool valid = frame < a.batch;
-        const T* xf = a.x + (valid ? frame : 0) * (int64_t)(2 * M);
+        const T* xf = a.x + (valid ? frame : 0) * a.frame_stride;
         C v[P];
 
         // ---------------- pass 0: global load (+window) -> butterfly -> LDS ----------------

@@ -1,0 +1,281 @@
+// stft.hip — short-time |FFT| + per-frame peak of interleaved PCM16 audio (BASELINE config 3).
+//
+// The reference has no STFT; it is the north-star extension of the same hot path
+// (window -> real FFT -> |Y| -> peak, main.py:475-479, 1029) to overlapping frames of a long record,
+// with the int16 -> float scaling of the reference's own import path (int16 / 32768, versão15.py:637).
+//
+// Stereo (channels == 2): frame f of BOTH channels is ONE complex transform of length nfft,
+//   z[j] = w[j] (L[j] + i R[j]) — each interleaved (L,R) int16 pair is one 4-byte coalesced load —
+//   and the channels are separated by Hermitian symmetry in the epilogue:
+//   L^[k] = (Z[k] + conj Z[N-k]) / 2,   R^[k] = (Z[k] - conj Z[N-k]) / (2i).
+//   Every loaded byte is used; the 75 %-overlap re-reads of neighbouring frames are served by L2 / MALL.
+// Other channel counts: a de-interleave + convert pass, then the batched rfft kernels with
+//   frame stride = hop.
+// Output layout: mag[channel][frame][nfft/2+1], peak_bin / peak_mag[channel][frame].
+#include <string.h>
+
+#include <vector>
+
+#include "lds_fft.h"
+#include "runtime.h"
+
+namespace sa {
+
+template <typename T>
+int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32_t n, int32_t window, double win_param,
+                          int32_t flags, T* mag, int32_t* peak_bin, T* peak_mag, hipStream_t st);
+
+struct StftArgs {
+    const int16_t* pcm;     // interleaved stereo
+    int64_t nframes;        // STFT frames per channel
+    int64_t hop;
+    const float* win;       // [nfft] or nullptr
+    const float2* twR;      // w_N^i
+    int flags;
+    float* mag;             // [2][nframes][N/2+1]
+    int32_t* peak_bin;      // [2][nframes]
+    float* peak_mag;        // [2][nframes]
+};
+
+template <int LR>
+__global__ void __launch_bounds__(FftPlan<LR>::TPF) stft_stereo_kernel(StftArgs a) {
+    using PL = FftPlan<LR>;
+    constexpr int N = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
+    constexpr int S = LdsPadShift<float>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* buf = reinterpret_cast<float2*>(smem_raw);
+    constexpr int NW = (TPF + 63) / 64;
+    float* red_m = reinterpret_cast<float*>(buf + lds_fft_elems<float, LR>());
+    int* red_k = reinterpret_cast<int*>(red_m + 2 * NW);
+    const int tl = threadIdx.x;
+    const float scale = 1.0f / 32768.0f;
+    const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
+    const bool wdb = a.flags & SA_F_DB;
+    const bool excl = a.flags & SA_F_EXCLUDE_DC_NYQ;
+    constexpr int NB = N / 2 + 1;
+    for (int64_t f = blockIdx.x; f < a.nframes; f += gridDim.x) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.pcm) + f * a.hop;   // one (L,R) pair per dword
+        float2 v[P];
+#pragma unroll
+        for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; ++n1) {
+                const int j = n1 * (N / R0) + tl + TPF * u;
+                const uint32_t lr = src[j];
+                float l = (float)(int16_t)(lr & 0xFFFF) * scale, r = (float)(int16_t)(lr >> 16) * scale;
+                if (a.win) { const float w = a.win[j]; l *= w; r *= w; }
+                v[u * R0 + n1] = mk<float>(l, r);
+            }
+        lds_fft<float, LR>(v, buf, tl, a.twR);
+        // ---- split channels, magnitudes, peaks ------------------------------------------------------
+        float bl = -1.f, br = -1.f;
+        int kl = 0x7fffffff, kr = 0x7fffffff;
+        float* ml = wmag ? a.mag + f * NB : nullptr;
+        float* mr = wmag ? a.mag + (a.nframes + f) * NB : nullptr;
+#pragma unroll
+        for (int u = 0; u < (NB + TPF - 1) / TPF; ++u) {
+            const int q = tl + TPF * u;                 // ascending per thread: first max kept with '>'
+            if (q < NB) {
+                const float2 zq = buf[lds_pad<S>(q)];
+                const float2 zm = buf[lds_pad<S>((N - q) & (N - 1))];
+                const float2 L = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
+                const float2 Rr = mk<float>(0.5f * (zq.y + zm.y), 0.5f * (zm.x - zq.x));
+                const float mL = sqrtf(L.x * L.x + L.y * L.y), mR = sqrtf(Rr.x * Rr.x + Rr.y * Rr.y);
+                if (wmag) {
+                    ml[q] = wdb ? 20.0f * log10f(fmaxf(mL, SA_DB_FLOOR_F32)) : mL;
+                    mr[q] = wdb ? 20.0f * log10f(fmaxf(mR, SA_DB_FLOOR_F32)) : mR;
+                }
+                if (!(excl && (q == 0 || q == N / 2))) {
+                    if (mL > bl) { bl = mL; kl = q; }
+                    if (mR > br) { br = mR; kr = q; }
+                }
+            }
+        }
+        constexpr int WRED = TPF < 64 ? TPF : 64;
+#pragma unroll
+        for (int off = WRED / 2; off > 0; off >>= 1) {
+            const float ol = __shfl_xor(bl, off), orr = __shfl_xor(br, off);
+            const int okl = __shfl_xor(kl, off), okr = __shfl_xor(kr, off);
+            if (ol > bl || (ol == bl && okl < kl)) { bl = ol; kl = okl; }
+            if (orr > br || (orr == br && okr < kr)) { br = orr; kr = okr; }
+        }
+        if constexpr (TPF > 64) {
+            const int wave = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) { red_m[2 * wave] = bl; red_m[2 * wave + 1] = br; red_k[2 * wave] = kl; red_k[2 * wave + 1] = kr; }
+            __syncthreads();
+            if (tl == 0)
+                for (int w = 1; w < NW; ++w) {
+                    const float ol = red_m[2 * w], orr = red_m[2 * w + 1];
+                    const int okl = red_k[2 * w], okr = red_k[2 * w + 1];
+                    if (ol > bl || (ol == bl && okl < kl)) { bl = ol; kl = okl; }
+                    if (orr > br || (orr == br && okr < kr)) { br = orr; kr = okr; }
+                }
+        }
+        if (tl == 0) {
+            a.peak_bin[f] = kl; a.peak_mag[f] = bl;
+            a.peak_bin[a.nframes + f] = kr; a.peak_mag[a.nframes + f] = br;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void deinterleave_pcm16(const int16_t* __restrict__ pcm, float* __restrict__ out, int64_t n, int channels, int ch) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)pcm[i * channels + ch] * (1.0f / 32768.0f);
+}
+
+struct TwF32Ctx { int64_t n; };
+static void fill_tw32(void* host, void* ctx) {
+    const int64_t n = static_cast<TwF32Ctx*>(ctx)->n;
+    std::vector<double> t;
+    host_twiddle(n, n, 1, t);
+    float* o = static_cast<float*>(host);
+    for (size_t i = 0; i < t.size(); ++i) o[i] = (float)t[i];
+}
+struct WinF32Ctx { int w; double p; int64_t n; };
+static void fill_win32(void* host, void* ctx) {
+    WinF32Ctx* c = static_cast<WinF32Ctx*>(ctx);
+    std::vector<double> w;
+    host_window(c->w, c->p, (int)c->n, w);
+    float* o = static_cast<float*>(host);
+    for (size_t i = 0; i < w.size(); ++i) o[i] = (float)w[i];
+}
+
+template <int LR>
+static int launch_stereo(const StftArgs& a, hipStream_t st) {
+    constexpr int NW = (FftPlan<LR>::TPF + 63) / 64;
+    constexpr int lds = lds_fft_elems<float, LR>() * 8 + NW * 16 + 16;
+    auto kern = stft_stereo_kernel<LR>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int64_t cap = (int64_t)num_cus() * 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.nframes < cap ? a.nframes : cap)), dim3(FftPlan<LR>::TPF), lds, st, a);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+int stft_pcm16_dev(const int16_t* pcm, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop, int32_t window,
+                   double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, float* scratch,
+                   hipStream_t st) {
+    SA_TRY(ensure_init());
+    int lr = 0;
+    while ((1 << lr) < nfft) ++lr;
+    if (nfft < 16 || (1 << lr) != nfft || nfft > 16384) { set_error("stft: nfft=%d must be a power of two in [16, 16384]", nfft); return SA_EUNSUP; }
+    if (hop < 1) { set_error("stft: hop must be >= 1"); return SA_EINVAL; }
+    if (channels < 1) { set_error("stft: channels must be >= 1"); return SA_EINVAL; }
+    if (window < SA_WIN_NONE || window > SA_WIN_GAUSSIAN) { set_error("unknown window id %d", window); return SA_EINVAL; }
+    if (flags & ~7) { set_error("stft: unknown flag bits"); return SA_EINVAL; }
+    if (n_samples < nfft) return SA_OK;                 // no complete frame
+    const int64_t nframes = (n_samples - nfft) / hop + 1;
+    if (!pcm || !peak_bin || !peak_mag || ((flags & SA_F_WRITE_MAG) && !mag)) { set_error("stft: NULL buffer"); return SA_EINVAL; }
+    if (channels == 2 && nfft <= 8192) {
+        StftArgs a{};
+        a.pcm = pcm; a.nframes = nframes; a.hop = hop; a.flags = flags; a.mag = mag; a.peak_bin = peak_bin; a.peak_mag = peak_mag;
+        TwF32Ctx tc{nfft};
+        a.twR = static_cast<const float2*>(get_cached_table("tw32:" + std::to_string(nfft), (size_t)nfft * 8, fill_tw32, &tc));
+        if (!a.twR) return SA_EHIP;
+        if (window != SA_WIN_NONE) {
+            WinF32Ctx wc{window, win_param, nfft};
+            char key[96];
+            snprintf(key, sizeof(key), "win32:%d:%.17g:%d", window, window == SA_WIN_GAUSSIAN ? win_param : 0.0, nfft);
+            a.win = static_cast<const float*>(get_cached_table(key, (size_t)nfft * 4, fill_win32, &wc));
+            if (!a.win) return SA_EHIP;
+        }
+        switch (lr) {
+            case 4: return launch_stereo<4>(a, st);
+            case 5: return launch_stereo<5>(a, st);
+            case 6: return launch_stereo<6>(a, st);
+            case 7: return launch_stereo<7>(a, st);
+            case 8: return launch_stereo<8>(a, st);
+            case 9: return launch_stereo<9>(a, st);
+            case 10: return launch_stereo<10>(a, st);
+            case 11: return launch_stereo<11>(a, st);
+            case 12: return launch_stereo<12>(a, st);
+            case 13: return launch_stereo<13>(a, st);
+        }
+    }
+    // generic channel count: de-interleave + convert, then strided batched rfft
+    if (hop % 2) { set_error("stft: odd hop is only supported for stereo input with nfft <= 8192"); return SA_EUNSUP; }
+    if (!scratch) { set_error("stft: this channel layout needs a scratch buffer of n_samples floats"); return SA_EINVAL; }
+    const int64_t nb = nfft / 2 + 1;
+    for (int ch = 0; ch < channels; ++ch) {
+        hipLaunchKernelGGL(deinterleave_pcm16, dim3(num_cus() * 8), dim3(256), 0, st, pcm, scratch, n_samples, channels, ch);
+        SA_HIP(hipGetLastError());
+        SA_TRY(rfft_peak_strided_dev<float>(scratch, nframes, hop, nfft, window, win_param, flags,
+                                            mag ? mag + (int64_t)ch * nframes * nb : nullptr, peak_bin + (int64_t)ch * nframes,
+                                            peak_mag + (int64_t)ch * nframes, st));
+    }
+    return SA_OK;
+}
+
+}  // namespace sa
+
+extern "C" {
+
+int64_t sa_stft_num_frames(int64_t n_samples, int32_t nfft, int32_t hop) {
+    if (hop < 1 || nfft < 1 || n_samples < nfft) return 0;
+    return (n_samples - nfft) / hop + 1;
+}
+
+int sa_stft_pcm16_dev(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop,
+                      int32_t window, double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag,
+                      float* scratch, void* stream) {
+    SA_TRY(sa::ensure_init());
+    hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
+    return sa::stft_pcm16_dev(interleaved, n_samples, channels, nfft, hop, window, win_param, flags, mag, peak_bin, peak_mag,
+                              scratch, st);
+}
+
+int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop, int32_t window,
+                  double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag) {
+    using namespace sa;
+    SA_TRY(ensure_init());
+    if (channels < 1 || nfft < 1 || hop < 1) { set_error("stft: bad channels/nfft/hop"); return SA_EINVAL; }
+    const int64_t nframes = sa_stft_num_frames(n_samples, nfft, hop);
+    if (nframes == 0) return SA_OK;
+    if (!interleaved) { set_error("stft: NULL input"); return SA_EINVAL; }
+    hipStream_t st = thread_stream();
+    const int64_t nb = nfft / 2 + 1;
+    // process in segments of frames so the staging buffers stay bounded (<= ~1 GiB of spectra)
+    int64_t seg = (int64_t)(1ull << 30) / (nb * 4 * channels);
+    if (seg < 1) seg = 1;
+    if (seg > nframes) seg = nframes;
+    const int64_t seg_samples = (seg - 1) * hop + nfft;
+    int16_t* dpcm = nullptr;
+    float *dmag = nullptr, *dpm = nullptr, *dscr = nullptr;
+    int32_t* dpb = nullptr;
+    const bool wmag = flags & SA_F_WRITE_MAG;
+    hipError_t e = hipMalloc(&dpcm, (size_t)seg_samples * channels * 2);
+    if (e == hipSuccess && wmag) e = hipMalloc(&dmag, (size_t)seg * nb * channels * 4);
+    if (e == hipSuccess) e = hipMalloc(&dpm, (size_t)seg * channels * 4);
+    if (e == hipSuccess) e = hipMalloc(&dpb, (size_t)seg * channels * 4);
+    if (e == hipSuccess && !(channels == 2 && nfft <= 8192)) e = hipMalloc(&dscr, (size_t)seg_samples * 4);
+    int rc = SA_OK;
+    if (e != hipSuccess) { set_error("stft: hipMalloc failed: %s", hipGetErrorString(e)); rc = SA_ENOMEM; }
+    for (int64_t f0 = 0; rc == SA_OK && f0 < nframes; f0 += seg) {
+        const int64_t nf = nframes - f0 < seg ? nframes - f0 : seg;
+        const int64_t ns = (nf - 1) * hop + nfft;
+        e = hipMemcpyAsync(dpcm, interleaved + f0 * hop * channels, (size_t)ns * channels * 2, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { set_error("stft: H2D failed: %s", hipGetErrorString(e)); rc = SA_EHIP; break; }
+        rc = stft_pcm16_dev(dpcm, ns, channels, nfft, hop, window, win_param, flags, dmag, dpb, dpm, dscr, st);
+        if (rc != SA_OK) break;
+        for (int ch = 0; ch < channels && e == hipSuccess; ++ch) {
+            if (wmag) e = hipMemcpyAsync(mag + ((int64_t)ch * nframes + f0) * nb, dmag + (int64_t)ch * nf * nb, (size_t)nf * nb * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(peak_bin + (int64_t)ch * nframes + f0, dpb + (int64_t)ch * nf, (size_t)nf * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(peak_mag + (int64_t)ch * nframes + f0, dpm + (int64_t)ch * nf, (size_t)nf * 4, hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("stft: D2H failed: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+    }
+    if (dpcm) hipFree(dpcm);
+    if (dmag) hipFree(dmag);
+    if (dpm) hipFree(dpm);
+    if (dpb) hipFree(dpb);
+    if (dscr) hipFree(dscr);
+    return rc;
+}
+
+}  // extern "C"

@@ -164,6 +164,21 @@ int sa_synth_f64(const sa_gen_params* p, double* t_out, double* y_out);
 int sa_compute_f64(const sa_gen_params* p, int32_t window, double win_param, int32_t flags, double* t_out,
                    double* y_out, double* mag, int32_t* peak_bin, double* peak_mag);
 
+/* ---- BASELINE config 3: short-time |FFT| + per-frame peak of interleaved PCM16 audio --------------
+ * Same per-frame arithmetic as above (window -> rfft -> |Y| -> peak; main.py:475-479, 1029) over
+ * overlapping frames f = 0 .. (n_samples - nfft)/hop of every channel; samples are scaled int16/32768
+ * as in the reference's own import path (versão15.py:637).  The reference has no STFT.
+ *   interleaved [n_samples][channels] int16
+ *   mag         [channels][frames][nfft/2+1] float (SA_F_WRITE_MAG), peak_bin / peak_mag [channels][frames]
+ * nfft: power of two 16..8192 (stereo fast path: both channels in one complex transform) or ..16384.
+ * `scratch` (device variant): n_samples floats, only needed when channels != 2 or nfft > 8192. */
+int64_t sa_stft_num_frames(int64_t n_samples, int32_t nfft, int32_t hop);
+int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop,
+                  int32_t window, double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag);
+int sa_stft_pcm16_dev(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop,
+                      int32_t window, double win_param, int32_t flags, float* mag, int32_t* peak_bin,
+                      float* peak_mag, float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -314,3 +314,22 @@ def cubic_spline_notaknot(xk, yk, xq):
     idx = np.clip(np.searchsorted(xk, xq, side="right") - 1, 0, n - 2)
     h = xq - xk[idx]
     return ((c3[idx] * h + c2[idx]) * h + c1[idx]) * h + c0[idx]
+
+
+# ---- BASELINE config 3: STFT of PCM16 (north-star extension; oracle = strided np.fft.rfft frames) ----
+def stft_pcm16(pcm, nfft, hop, win="blackman", win_param=0.0, exclude_dc_nyq=False):
+    """pcm int16 [n_samples, channels] -> (mag f64 [ch, frames, nfft/2+1], peak_bin [ch, frames], peak_mag).
+    Frames f = 0..(n-nfft)//hop, no padding; samples scaled int16/32768 (versão15.py:637)."""
+    pcm = np.asarray(pcm)
+    if pcm.ndim == 1:
+        pcm = pcm[:, None]
+    ns, ch = pcm.shape
+    nf = (ns - nfft) // hop + 1 if ns >= nfft else 0
+    w = window(win, nfft, win_param)
+    mags, pbs, pms = [], [], []
+    for c in range(ch):
+        x = pcm[:, c].astype(np.float32) * np.float32(1.0 / 32768.0)
+        fr = np.lib.stride_tricks.sliding_window_view(x, nfft)[::hop][:nf]
+        m, pb, pm = rfft_mag_peak(fr, win, win_param, exclude_dc_nyq=exclude_dc_nyq)
+        mags.append(m); pbs.append(pb); pms.append(pm)
+    return np.stack(mags), np.stack(pbs), np.stack(pms)

@@ -1,0 +1,58 @@
+"""GPU parity: PCM16 STFT (BASELINE config 3 shape, reduced length) vs strided numpy rfft frames."""
+import numpy as np
+import pytest
+
+from oracle import spectrum_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_pcm(ns, ch, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(ns) / 44100.0
+    cols = []
+    for c in range(ch):
+        f0 = 440.0 * (c + 1)
+        x = 0.4 * np.sin(2 * np.pi * f0 * t) + 0.3 * np.sin(2 * np.pi * (3000.0 + 2000.0 * t / t[-1]) * t) + 0.05 * rng.standard_normal(ns)
+        cols.append(x)
+    x = np.stack(cols, axis=1)
+    return np.clip(np.round(x * 32767), -32768, 32767).astype(np.int16)
+
+
+def check(pcm, nfft, hop, win):
+    import fft_amd
+    mag, pb, pm = fft_amd.stft_pcm16(pcm, nfft, hop, win)
+    mref, pbref, pmref = O.stft_pcm16(pcm, nfft, hop, win)
+    assert mag.shape == mref.shape
+    rel = np.linalg.norm(mag - mref, axis=-1) / np.maximum(np.linalg.norm(mref, axis=-1), 1e-30)
+    assert rel.max() < 1e-5 * np.log2(nfft)
+    bad = np.nonzero(pb != pbref)
+    if len(bad[0]):
+        gap = O.top2_gap(mref[bad])
+        assert (gap < 1e-5).all()
+    np.testing.assert_allclose(pm, pmref, rtol=2e-4)
+
+
+@pytest.mark.parametrize("nfft,hop", [(8192, 2048), (1024, 256), (64, 17), (4096, 4096), (256, 1)])
+def test_stft_stereo(nfft, hop):
+    check(synth_pcm(nfft * 6 + 123, 2, nfft), nfft, hop, "blackman")
+
+
+@pytest.mark.parametrize("ch", [1, 3])
+def test_stft_other_channel_counts(ch):
+    check(synth_pcm(30000, ch, ch), 4096, 1024, "hann")
+    check(synth_pcm(30000, ch, ch), 2048, 512, "none")
+
+
+def test_stft_edges():
+    import fft_amd
+    mag, pb, pm = fft_amd.stft_pcm16(np.zeros((100, 2), np.int16), 1024, 256)       # shorter than one frame
+    assert mag.shape == (2, 0, 513) and pb.shape == (2, 0)
+    pcm = np.zeros((8192, 2), np.int16); pcm[:, 0] = 16384                          # exactly one frame; DC on L, silence on R
+    mag, pb, pm = fft_amd.stft_pcm16(pcm, 8192, 2048, "none")
+    assert mag.shape == (2, 1, 4097) and pb[0, 0] == 0 and pm[0, 0] == pytest.approx(4096.0, rel=1e-6)
+    assert mag[1].max() == 0.0
+    with pytest.raises(ValueError):
+        fft_amd.stft_pcm16(np.zeros((5000, 2), np.int16), 1000, 250)                # nfft not a power of two
+    with pytest.raises(ValueError):
+        fft_amd.stft_pcm16(np.zeros((5000, 2), np.float32), 1024, 256)
