@@ -46,6 +46,8 @@ PROTOTYPES = {
     "sa_fft_c2c_f64_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "sa_fft_mag_f64": (C.c_int, [_vp, _i64, _i64, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "sa_synth_f64": (C.c_int, [_vp, _vp, _vp]),
+    "sa_synth_analyze": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp]),
+    "sa_synth_analyze_dev": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sa_stft_num_frames": (_i64, [_i64, _i32, _i32]),
     "sa_stft_pcm16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "sa_stft_pcm16_dev": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),

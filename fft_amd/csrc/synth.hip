@@ -10,118 +10,13 @@
 // blocked prefix sum (numpy's cumsum is sequential: ~1e-15 relative drift, documented tolerance).
 // White noise uses a counter-based Philox stream: statistical parity only (the reference draws from
 // numpy's unseeded global RNG, main.py:553).
-#include <math.h>
-
-// numpy evaluates every product and sum separately; contraction into FMAs would move phases by an ulp
-#pragma clang fp contract(off)
-
-#include "fft_core.h"
+#include "synth_gen.h"
 #include "runtime.h"
 
 namespace sa {
 
 int fft_mag_any_dev(const double* dx, int64_t cnt, int64_t n, int window, double win_param, int flags, double* dmag,
                     int32_t* dpb, double* dpm, hipStream_t st);
-
-__device__ __forceinline__ double np_mod_2pi(double x) {
-    const double tp = 6.283185307179586;       // float64(2*pi), as numpy sees it
-    double r = fmod(x, tp);
-    if (r != 0.0 && r < 0.0) r += tp;
-    return r;
-}
-// scipy.signal.sawtooth(x, width)  (_waveforms.py:16)
-__device__ __forceinline__ double sp_sawtooth(double x, double width) {
-    const double pi = 3.141592653589793;
-    const double tmod = np_mod_2pi(x);
-    if (tmod < width * 6.283185307179586) return tmod / (pi * width) - 1.0;
-    return (pi * (width + 1.0) - tmod) / (pi * (1.0 - width));
-}
-// scipy.signal.square(x, duty)  (_waveforms.py:88)
-__device__ __forceinline__ double sp_square(double x, double duty) {
-    return np_mod_2pi(x) < duty * 6.283185307179586 ? 1.0 : -1.0;
-}
-__device__ __forceinline__ double np_sinc(double x) {   // sin(pi x)/(pi x), 1 at 0
-    const double y = 3.141592653589793 * (x == 0.0 ? 1.0e-20 : x);
-    return sin(y) / y;
-}
-
-__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                           uint32_t* out) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// One sample of _generate_waveform (main.py:536-615), before the vpp/2 scaling.
-__device__ double gen_sample(const sa_gen_params& p, int64_t n, double tmean) {
-    const double pi = 3.141592653589793, two_pi = 6.283185307179586;
-    const double t = (double)n / p.Fs;                     // np.arange(N)/Fs  (main.py:460)
-    const double tl = (double)(p.N - 1) / p.Fs;            // t[-1]
-    const double Fc = p.Fc, Fm = p.Fm, dur = p.duration;
-    const double x = two_pi * Fc * t;                      // ((2*pi)*Fc)*t, numpy's left-to-right order
-    switch (p.waveform) {
-        case SA_WF_SENO: return sin(x);
-        case SA_WF_COSSENO: return cos(x);
-        case SA_WF_QUADRADA: return sp_square(x, 0.5);
-        case SA_WF_TRIANGULAR: return sp_sawtooth(x, 0.5);
-        case SA_WF_DENTE_DE_SERRA: return sp_sawtooth(x, 1.0);
-        case SA_WF_PULSO: return sp_square(x, 0.2);
-        case SA_WF_RUIDO_BRANCO: {
-            uint32_t r[4];
-            philox4x32((uint32_t)(n >> 1), (uint32_t)((uint64_t)n >> 33), 0x6E6F6973u, 0u, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
-            const double u1 = ((double)r[0] + 0.5) / 4294967296.0, u2 = ((double)r[1] + 0.5) / 4294967296.0;
-            const double rad = sqrt(-2.0 * log(u1));
-            return 0.5 * rad * ((n & 1) ? sin(two_pi * u2) : cos(two_pi * u2));
-        }
-        case SA_WF_EXP_DECAIMENTO: return exp(-t / (dur / 5.0)) * sin(x);
-        case SA_WF_PASSO: { const double tq = (double)(p.N / 4) / p.Fs; return (t - tq) >= 0.0 ? 1.0 : 0.0; }   // heaviside(.,1)
-        case SA_WF_RAMPA: return t / tl;
-        case SA_WF_PARABOLA: { const double r = t / tl; return r * r; }
-        case SA_WF_IMPULSO: return n == p.N / 2 ? 1.0 : 0.0;
-        case SA_WF_TANGENTE: { const double v = tan(pi * Fc * t); return fmin(fmax(v, -10.0), 10.0); }
-        case SA_WF_SINC: return np_sinc(2.0 * Fc * t);
-        case SA_WF_GAUSSIANA: { const double d = t - tmean, s = 0.1 * dur; return exp(-(d * d) / (s * s)) * sin(x); }
-        case SA_WF_CHIRP_LINEAR: {         // scipy chirp 'linear': cos(2 pi (f0 t + 0.5 beta t^2)), f1 = 5 Fc, t1 = t[-1]
-            const double beta = (5.0 * Fc - Fc) / tl;
-            return cos(two_pi * (Fc * t + 0.5 * beta * t * t));
-        }
-        case SA_WF_CHIRP_QUADRATICO: {     // 'quadratic', vertex_zero: cos(2 pi (f0 t + beta t^3/3)), f1 = 10 Fc
-            const double beta = (10.0 * Fc - Fc) / (tl * tl);
-            return cos(two_pi * (Fc * t + beta * (t * t * t) / 3.0));
-        }
-        case SA_WF_ONDA_AM: return (1.0 + 0.5 * sin(two_pi * Fm * t)) * sin(x);
-        case SA_WF_ONDA_FM: return sin(x + 5.0 * sin(two_pi * Fm * t));
-        case SA_WF_BATIMENTO: return sin(x) + sin(two_pi * (Fc + Fm) * t);
-        case SA_WF_LORENTZIANA: return 1.0 / (1.0 + x * x);
-        case SA_WF_HIPERBOLICA: return sinh(x);
-        case SA_WF_BESSEL: return j0(x);
-        case SA_WF_SINC_MODULADO: return np_sinc(2.0 * Fc * t) * sin(two_pi * Fm * t);
-        case SA_WF_PULSO_GAUSSIANO: {       // scipy gausspulse(t, fc, bw=0.5, bwr=-6): exp(-a t^2) cos(2 pi fc t)
-            const double ref = pow(10.0, -6.0 / 20.0);
-            const double pb = pi * Fc * 0.5;
-            const double a = -(pb * pb) / (4.0 * log(ref));
-            return exp(-a * t * t) * cos(two_pi * Fc * t);
-        }
-        case SA_WF_DENTE_DE_SERRA_MOD: return sp_sawtooth(x, 0.3);
-        case SA_WF_ONDA_AM_DSB: return sin(x) * sin(two_pi * Fm * t);
-        case SA_WF_ONDA_FM_ESTEREO: {
-            const double m = 3.0 * sin(two_pi * Fm * t);
-            return 0.5 * (sin(x + m) + sin(two_pi * (Fc + 1000.0) * t + m));
-        }
-        case SA_WF_QUADRADA_MODULADA: return sp_square(x, 0.5) * (1.0 + 0.5 * sin(two_pi * Fm * t));
-        case SA_WF_TRIANGULAR_MODULADA: return sp_sawtooth(x, 0.5) * (1.0 + 0.3 * sin(two_pi * Fm * t));
-        case SA_WF_PULSO_EXPONENCIAL: return exp(-5.0 * t / dur) * sin(x);
-        case SA_WF_ONDA_COMB: { const double v = sin(x) + 0.7; return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0); }
-        case SA_WF_ONDA_HARMONICA: return sin(x) + 0.5 * sin(two_pi * 2.0 * Fc * t);
-        default: return 0.0;                // unknown name -> np.zeros_like(t)  (main.py:614-615)
-    }
-}
 
 __global__ void synth_kernel(sa_gen_params p, double* __restrict__ y, double* __restrict__ t_out) {
     const double two_pi = 6.283185307179586;

@@ -179,6 +179,21 @@ int sa_stft_pcm16_dev(const int16_t* interleaved, int64_t n_samples, int32_t cha
                       int32_t window, double win_param, int32_t flags, float* mag, int32_t* peak_bin,
                       float* peak_mag, float* scratch, void* stream);
 
+/* ---- BASELINE config 4: fused generator pipeline, fp32 spectra, no HBM input ------------------------
+ * Per parameter record:  synthesis + AM/FM at n_base points (main.py:460-472, 536-629; the record's N is
+ * ignored and taken as n_base)  ->  `upsample`x not-a-knot cubic spline evaluated on
+ * np.linspace(t[0], t[-1], n_base*upsample) (scipy CubicSpline as used at main.py:1390-1392)
+ * ->  window  ->  rfft  ->  |Y| (-> dB)  ->  peak (main.py:475-479, 1029).
+ * upsample: 1 or 8; n_base*upsample: power of two 2048..16384; n_base >= 256.
+ *   params [batch] (host or device resident for the _dev variant), mag [batch][n/2+1],
+ *   y_out  [batch][n] upsampled time signal (may be NULL). */
+int sa_synth_analyze(const sa_gen_params* params, int64_t batch, int32_t n_base, int32_t upsample,
+                     int32_t window, double win_param, int32_t flags, float* mag, int32_t* peak_bin,
+                     float* peak_mag, float* y_out);
+int sa_synth_analyze_dev(const sa_gen_params* params_dev, int64_t batch, int32_t n_base, int32_t upsample,
+                         int32_t window, double win_param, int32_t flags, float* mag, int32_t* peak_bin,
+                         float* peak_mag, float* y_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

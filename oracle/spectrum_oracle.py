@@ -333,3 +333,27 @@ def stft_pcm16(pcm, nfft, hop, win="blackman", win_param=0.0, exclude_dc_nyq=Fal
         m, pb, pm = rfft_mag_peak(fr, win, win_param, exclude_dc_nyq=exclude_dc_nyq)
         mags.append(m); pbs.append(pb); pms.append(pm)
     return np.stack(mags), np.stack(pbs), np.stack(pms)
+
+
+# ---- BASELINE config 4: fused generator pipeline (north-star composition of reference pieces) ---------
+def synth_upsample_analyze(p, vpp=None, n_base=2048, upsample=8, win="gaussian", win_param=0.0):
+    """compute-path samples at n_base points (main.py:460-472) -> CubicSpline(t, y)(np.linspace(t0, t_last,
+    n_base*upsample)) exactly as the zoom path does it (main.py:1390-1392) -> window -> rfft -> |Y|, peak.
+    Returns (y_up f64 [n], mag f64 [n/2+1], peak_bin, peak_mag)."""
+    from scipy.interpolate import CubicSpline
+    q = dict(p)
+    q["N"] = n_base
+    t = np.arange(n_base) / q["Fs"]
+    y = generate_waveform(q, t)
+    if vpp is not None:
+        y = y * (vpp / 2)
+    if not q["waveform"].startswith("Onda AM") and not q["waveform"].startswith("Onda FM"):
+        y = apply_modulation(q, y, t)
+    y = y.astype(np.float32).astype(np.float64)            # the device keeps base samples in fp32
+    n = n_base * upsample
+    if upsample > 1:
+        yu = CubicSpline(t, y)(np.linspace(t[0], t[-1], n))
+    else:
+        yu = y
+    mag, pb, pm = rfft_mag_peak(yu[None, :], win, win_param)
+    return yu, mag[0], int(pb[0]), float(pm[0])

@@ -1,0 +1,69 @@
+"""GPU parity: fused generator pipeline (BASELINE config 4) vs reference-style numpy/scipy composition."""
+import numpy as np
+import pytest
+
+from fft_amd import specengine as S
+from oracle import spectrum_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_params(n, seed, n_base=2048, fs=100e3):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        f0 = rng.uniform(1e3, 5e3)
+        mode = i % 4
+        out.append({"duration": n_base / fs, "Fc": f0, "Fs": fs, "Fm": rng.uniform(10, 200), "waveform": "Chirp Linear",
+                    "am_on": mode in (1, 3), "am_depth": rng.uniform(0, 1), "fm_on": mode in (2, 3), "fm_dev": rng.uniform(0, 500)})
+    return out
+
+
+@pytest.mark.parametrize("n_base,upsample", [(2048, 8), (256, 8), (1024, 8), (2048, 1), (16384, 1)])
+def test_pipeline_matches_oracle(n_base, upsample):
+    params = make_params(12, n_base + upsample, n_base)
+    mag, pb, pm, y = S.synth_analyze(params, 2.0, n_base, upsample, "gaussian", return_signal=True)
+    n = n_base * upsample
+    assert mag.shape == (12, n // 2 + 1) and y.shape == (12, n)
+    for i, p in enumerate(params):
+        yu, mref, pbref, pmref = O.synth_upsample_analyze(p, 2.0, n_base, upsample, "gaussian")
+        assert np.abs(y[i] - yu).max() < 2e-5, (i, np.abs(y[i] - yu).max())          # fp32 samples, O(1) amplitude
+        rel = np.linalg.norm(mag[i] - mref) / np.linalg.norm(mref)
+        assert rel < 1e-5 * np.log2(n), (i, rel)
+        if pb[i] != pbref:
+            assert O.top2_gap(mref[None])[0] < 1e-4
+        assert pm[i] == pytest.approx(pmref, rel=1e-3)
+
+
+def test_pipeline_other_waveforms_and_windows():
+    fs, n_base = 100e3, 2048
+    base = {"duration": n_base / fs, "Fc": 2500.0, "Fs": fs, "Fm": 120.0, "am_on": False, "am_depth": 0.5, "fm_on": False, "fm_dev": 50.0}
+    params = [dict(base, waveform=w) for w in ["Seno", "Onda AM", "Onda FM", "Triangular", "Chirp Quadrático", "Batimento"]]
+    for win in ["hann", "none"]:
+        mag, pb, pm, y = S.synth_analyze(params, None, n_base, 8, win, return_signal=True)
+        for i, p in enumerate(params):
+            yu, mref, pbref, pmref = O.synth_upsample_analyze(p, None, n_base, 8, win)
+            assert np.abs(y[i] - yu).max() < 2e-5
+            assert np.linalg.norm(mag[i] - mref) / np.linalg.norm(mref) < 1e-5 * 14
+            assert pb[i] == pbref
+
+
+def test_spline_stage_alone_against_scipy_fixture_shape():
+    """Upsampled samples at the knots equal the base samples; spline is C2-smooth (second difference bounded)."""
+    fs, n_base = 100e3, 2048
+    p = {"duration": n_base / fs, "Fc": 3000.0, "Fs": fs, "Fm": 50.0, "waveform": "Seno", "am_on": False, "am_depth": 0, "fm_on": False, "fm_dev": 0}
+    _, _, _, y = S.synth_analyze([p], None, n_base, 8, "none", return_signal=True)
+    t, ybase = S.generate(dict(p, N=n_base))
+    assert abs(y[0, 0] - ybase[0]) < 1e-6 and abs(y[0, -1] - ybase[-1]) < 1e-6
+    tu = np.linspace(t[0], t[-1], n_base * 8)
+    assert np.abs(y[0] - np.sin(2 * np.pi * 3000.0 * tu)).max() < 5e-5      # spline error O(h^4) on a smooth sine
+
+
+def test_pipeline_argument_errors():
+    p = make_params(1, 0)
+    with pytest.raises(ValueError):
+        S.synth_analyze(p, None, 2048, 4)
+    with pytest.raises(ValueError):
+        S.synth_analyze(p, None, 1000, 8)
+    mag, pb, pm = S.synth_analyze([], None)
+    assert mag.shape == (0, 8193)
