@@ -44,6 +44,7 @@ PROTOTYPES = {
     "sa_fill_tone_noise_f32_dev": (C.c_int, [_vp, _i64, _i32, _dbl, _u64, _vp]),
     "sa_fft_c2c_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i32]),
     "sa_fft_c2c_f64_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "sa_twiddle_rows_f64_dev": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp]),
     "sa_fft_mag_f64": (C.c_int, [_vp, _i64, _i64, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "sa_synth_f64": (C.c_int, [_vp, _vp, _vp]),
     "sa_synth_analyze": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp]),

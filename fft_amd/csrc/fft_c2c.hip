@@ -286,9 +286,36 @@ int c2c_f64_dev(const double* in, double* out, double* work, int64_t n, int64_t 
     return run_final_multi(l3, a, st);
 }
 
+// data[r][c] *= w_n^{(row0 + r) * c}: the inter-GPU twiddle of the distributed four-step (rows = local
+// columns n2 of the global matrix, c = k1).
+__global__ void twiddle_rows_kernel(Cd* __restrict__ data, int64_t rows, int64_t cols, int64_t row0, int64_t n,
+                                    const Cd* __restrict__ tlo, const Cd* __restrict__ thi, int h) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i % cols;
+        const int64_t j = (int64_t)(((__int128)(row0 + r) * c) % n);
+        const Cd w = cmul(thi[j >> h], tlo[j & ((1LL << h) - 1)]);
+        data[i] = cmul(data[i], w);
+    }
+}
+
 }  // namespace sa
 
 extern "C" {
+
+int sa_twiddle_rows_f64_dev(double* data_ri, int64_t rows, int64_t cols, int64_t row0, int64_t n, void* stream) {
+    using namespace sa;
+    SA_TRY(ensure_init());
+    if (!data_ri || rows < 0 || cols < 0 || n < 2 || (n & (n - 1))) { set_error("sa_twiddle_rows_f64_dev: bad arguments"); return SA_EINVAL; }
+    if (rows == 0 || cols == 0) return SA_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : thread_stream();
+    C2cArgs a{};
+    SA_TRY(set_pass_twiddles(a, n));
+    hipLaunchKernelGGL(twiddle_rows_kernel, dim3(num_cus() * 8), dim3(256), 0, st, reinterpret_cast<Cd*>(data_ri), rows, cols, row0, n,
+                       a.tlo, a.thi, a.h);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
 
 int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_t n, int64_t batch, int32_t flags,
                        void* stream) {

@@ -116,6 +116,9 @@ int sa_fill_tone_noise_f32_dev(float* x, int64_t batch, int32_t n, double fs, ui
 int sa_fft_c2c_f64(const double* in_ri, double* out_ri, int64_t n, int64_t batch, int32_t flags);
 int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_t n, int64_t batch,
                        int32_t flags, void* stream);
+/* Inter-GPU twiddle of the distributed four-step (fft_amd/dist.py): data[r][c] *= w_n^{(row0 + r) c},
+ * data = rows x cols complex fp64 (device), n a power of two; exact index arithmetic, two-level table. */
+int sa_twiddle_rows_f64_dev(double* data_ri, int64_t rows, int64_t cols, int64_t row0, int64_t n, void* stream);
 
 /* ---- a6/a8/a9 for ARBITRARY frame length (the GUI drop-in path) ----------------------------------
  * |fft(y*w)| of real fp64 frames of any length n >= 1: bins 0..n/2, plus the dominant peak.
