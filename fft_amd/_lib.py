@@ -97,6 +97,14 @@ def check(rc):
     raise RuntimeError(msg)
 
 
+def torch_stream():
+    """Handle of torch's current HIP stream for the *_dev entry points. torch reports the legacy default
+    stream as 0, which the C ABI reads as "use the library's own stream": translate it to hipStreamLegacy (1)."""
+    import torch
+    h = torch.cuda.current_stream().cuda_stream
+    return _vp(h if h else 1)
+
+
 def ptr(a):
     """Pointer to a C-contiguous numpy array's data (or None)."""
     return None if a is None else a.ctypes.data_as(_vp)

@@ -71,7 +71,7 @@ class HipEngine:
         """a: complex128 [batch, n] contiguous device tensor; forward FFT of every row, in place."""
         import torch
         batch, n = a.shape
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = self._lib.torch_stream()
         work = None
         if n > 4096:
             if self._work is None or self._work.numel() < a.numel():
@@ -87,7 +87,7 @@ class HipEngine:
     def twiddle_rows(self, a, row0, n):
         import torch
         rows, cols = a.shape
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = self._lib.torch_stream()
         self._lib.check(self.lib.sa_twiddle_rows_f64_dev(self._ptr(a), rows, cols, int(row0), int(n), stream))
         return a
 

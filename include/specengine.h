@@ -16,7 +16,8 @@
  *     (thread local);
  *   - "host" entry points take host pointers, stage through device memory and synchronise before
  *     returning; "*_dev" entry points take device pointers, enqueue on `stream` (a hipStream_t cast
- *     to void*, NULL = the library's per-thread stream) and do NOT synchronise;
+ *     to void*, NULL = the library's own per-thread non-blocking stream) and do NOT synchronise; to enqueue
+ *     on the legacy default ("null") stream pass hipStreamLegacy, i.e. (void*)1, never a literal 0;
  *   - thread safe: may be called concurrently from several host threads (the reference calls the
  *     path from a ThreadPoolExecutor worker and from the Tk main thread, main.py:448, 745, 1080);
  *   - there is no CPU fallback: without a gfx950 device every compute entry point fails with SA_ENODEV.
