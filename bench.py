@@ -132,6 +132,13 @@ def main():
                                               max(args.steps, 5), C.byref(ms)))
     alg = ALG_BYTES_B if args.peak_only else ALG_BYTES_A
     achieved = alg * batch / (ms.value * 1e-3) / 1e9
+    # HBM traffic per launch from the PMC passes archived under profiles/ (rocprofv3 cannot run inside
+    # the bench): FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, scaled to this launch's frame count.
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic_c2.json")
+    if os.path.exists(tfile) and not args.peak_only:
+        tj = json.load(open(tfile))
+        traffic = tj["traffic_bytes_per_launch"] * batch / tj["frames_per_launch"]
 
     if rank == 0:
         # sanity: a sample of frames vs the CPU oracle (not timed)
@@ -158,7 +165,9 @@ def main():
                                    f" ({'peak only' if args.peak_only else 'spectrum+peak'}), device-resident",
                        "frames_per_gpu": batch, "n": n, "window": "hann", "parallelism": f"frame-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (PMC, profiles/hbm_traffic_c2.json)",
+                         "alg_bytes_per_launch": alg * batch,
                          "alg_bytes_per_frame": alg, "kernel_ms": ms.value},
             "parity_sample_ok": parity_ok,
         }
