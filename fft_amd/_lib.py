@@ -63,11 +63,33 @@ class GenParams(C.Structure):
                 ("fm_dev", _dbl), ("vpp_half", _dbl), ("seed", _u64)]
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 + HSA runtime.  If libspecengine.so is
+    loaded first it pulls in /opt/rocm's copy, and a later `import torch` then brings a second HSA
+    runtime into the process and finds no GPU.  When a torch wheel with a bundled runtime is
+    installed (it need not be imported) preload that copy, so the whole process shares ONE runtime
+    whatever the import order.  Without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:       # never fatal: fall back to the system runtime
+        pass
+
+
 def load():
     """Load libspecengine.so (once). Raises OSError with a build hint if it is not there."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} not found: build it with `make -C fft_amd/csrc` "
                       "(or python -c 'import __graft_entry__ as g; g.build()'). "

@@ -11,14 +11,14 @@
 
 namespace sa {
 
-template <int LR> struct FftPlan {
+template <int LR, int PP = 8> struct FftPlan {
     static constexpr int R = 1 << LR;
     static constexpr int N8 = LR / 3;
     static constexpr int REM = LR % 3;
     static constexpr int NP = N8 + (REM ? 1 : 0);
     static constexpr int radix(int j) { return j < N8 ? 8 : (1 << REM); }
     static constexpr int H(int j) { int h = 1; for (int i = 0; i < j; ++i) h *= radix(i); return h; }
-    static constexpr int P = LR >= 3 ? 8 : R;                 // points per thread
+    static constexpr int P = LR >= 3 ? PP : R;                // points per thread (8, or 16 for the largest frames)
     static constexpr int TPF = R / P;                          // threads per transform
 };
 
@@ -33,12 +33,28 @@ template <typename T, int LR> constexpr int lds_fft_elems() {
     return n;
 }
 
+// v[k] *= w^k, k = 1..RJ-1: ONE table load per butterfly, the powers come from a product tree of depth <= 3
+// (a few ulp; keeps the vector-memory path free for the frame data instead of 7 scattered twiddle loads).
+template <typename T, int RJ, typename C>
+__device__ __forceinline__ void apply_twiddle_powers(C* v, C w) {
+    if constexpr (RJ == 2) {
+        v[1] = cmul(v[1], w);
+    } else if constexpr (RJ == 4) {
+        const C w2 = cmul(w, w);
+        v[1] = cmul(v[1], w); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], cmul(w2, w));
+    } else {
+        const C w2 = cmul(w, w), w3 = cmul(w2, w), w4 = cmul(w2, w2);
+        v[1] = cmul(v[1], w); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+        v[5] = cmul(v[5], cmul(w4, w)); v[6] = cmul(v[6], cmul(w4, w2)); v[7] = cmul(v[7], cmul(w4, w3));
+    }
+}
+
 // Input convention: v[u * R0 + n1] = x[n1 * (R / R0) + (tl + TPF * u)],  R0 = first radix, u < P / R0.
 // twR[i] = w_R^i, i < R (global or LDS table).
-template <typename T, int LR>
+template <typename T, int LR, int PP = 8>
 __device__ __forceinline__ void lds_fft(cplx<T>* v, cplx<T>* buf, int tl, const cplx<T>* __restrict__ twR) {
     using C = cplx<T>;
-    using PL = FftPlan<LR>;
+    using PL = FftPlan<LR, PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF;
     constexpr int S = LdsPadShift<T>::value;
     {
@@ -48,10 +64,7 @@ __device__ __forceinline__ void lds_fft(cplx<T>* v, cplx<T>* buf, int tl, const 
         for (int u = 0; u < P / R0; ++u) {
             const int id = tl + TPF * u;
             bfly<T, R0>(&v[u * R0]);
-            if constexpr (PL::NP > 1) {
-#pragma unroll
-                for (int k = 1; k < R0; ++k) v[u * R0 + k] = cmul(v[u * R0 + k], twR[id * k]);
-            }
+            if constexpr (PL::NP > 1) apply_twiddle_powers<T, R0>(&v[u * R0], twR[id]);
 #pragma unroll
             for (int k = 0; k < R0; ++k) buf[lds_pad<S>(k * Mj + id)] = v[u * R0 + k];
         }
@@ -71,10 +84,7 @@ __device__ __forceinline__ void lds_fft(cplx<T>* v, cplx<T>* buf, int tl, const 
 #pragma unroll
                 for (int n = 0; n < 8; ++n) v[u * 8 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
                 bfly<T, 8>(&v[u * 8]);
-                if (Mj > 1) {
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) v[u * 8 + k] = cmul(v[u * 8 + k], twR[Hprev * mp * k]);
-                }
+                if (Mj > 1) apply_twiddle_powers<T, 8>(&v[u * 8], twR[Hprev * mp]);
             }
         } else if (Rj == 4) {
 #pragma unroll
@@ -84,10 +94,7 @@ __device__ __forceinline__ void lds_fft(cplx<T>* v, cplx<T>* buf, int tl, const 
 #pragma unroll
                 for (int n = 0; n < 4; ++n) v[u * 4 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
                 bfly<T, 4>(&v[u * 4]);
-                if (Mj > 1) {
-#pragma unroll
-                    for (int k = 1; k < 4; ++k) v[u * 4 + k] = cmul(v[u * 4 + k], twR[Hprev * mp * k]);
-                }
+                if (Mj > 1) apply_twiddle_powers<T, 4>(&v[u * 4], twR[Hprev * mp]);
             }
         } else {
 #pragma unroll

@@ -14,7 +14,7 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     constexpr int TPF = M / P;
     constexpr int FPW = TPF >= 256 ? 1 : 256 / TPF;
     constexpr int S = (sizeof(cplx<T>) == 8) ? 5 : 4;
-    constexpr int LDS_PER_FRAME = lds_pad_c<S>(M) + 1;
+    constexpr int LDS_PER_FRAME = lds_fft_elems<T, LOG2M>();
     constexpr int NTHREADS = TPF * FPW;
     constexpr int NWAVES = (NTHREADS + 63) / 64;
     constexpr size_t lds = (size_t)FPW * LDS_PER_FRAME * sizeof(cplx<T>) + NWAVES * (sizeof(T) + sizeof(int)) + 16;

@@ -10,7 +10,7 @@
 // One HBM read of the frame, one HBM write of the spectrum; twiddles / window come from small
 // L2-resident tables (the tuned n=4096 kernel in rfft4096.h keeps them in registers instead).
 #pragma once
-#include "fft_core.h"
+#include "lds_fft.h"
 
 namespace sa {
 
@@ -54,7 +54,7 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
     constexpr int M = 1 << LOG2M;
     constexpr int TPF = M / P;                       // threads per frame
     constexpr int S = (sizeof(C) == 8) ? 5 : 4;      // pad granule (elements per LDS bank row)
-    constexpr int LDS_PER_FRAME = lds_pad_c<S>(M) + 1;
+    constexpr int LDS_PER_FRAME = lds_fft_elems<T, LOG2M>();
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     C* smem = reinterpret_cast<C*>(smem_raw);
 
@@ -73,13 +73,13 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
         const T* xf = a.x + (valid ? frame : 0) * a.frame_stride;
         C v[P];
 
-        // ---------------- pass 0: global load (+window) -> butterfly -> LDS ----------------
+        // ---------------- global load (+window) into the first pass' registers, FFT through LDS -----
         {
             constexpr int R = PL::radix(0);
-            constexpr int Mj = M / R;                // tail length after this pass
+            constexpr int Mj = M / R;
 #pragma unroll
             for (int u = 0; u < P / R; ++u) {
-                const int id = tl + TPF * u;         // = m' (h = 0)
+                const int id = tl + TPF * u;
 #pragma unroll
                 for (int n1 = 0; n1 < R; ++n1) {
                     const int c = n1 * Mj + id;
@@ -90,70 +90,9 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                     }
                     v[u * R + n1] = z;
                 }
-                bfly<T, R>(&v[u * R]);
-                if constexpr (PL::NP > 1) {
-#pragma unroll
-                    for (int k = 1; k < R; ++k) v[u * R + k] = cmul(v[u * R + k], a.twM[id * k]);
-                }
-#pragma unroll
-                for (int k = 0; k < R; ++k) buf[lds_pad<S>(k * Mj + id)] = v[u * R + k];
             }
         }
-        // ---------------- passes 1 .. NP-1 --------------------------------------------------
-#pragma unroll
-        for (int j = 1; j < PL::NP; ++j) {
-            const int R = PL::radix(j);              // constant after unrolling
-            const int Hprev = PL::H(j);              // R_1..R_{j}   (heads so far)
-            const int Mprev = M / Hprev;             // tail length before this pass
-            const int Mj = Mprev / R;                // tail length after this pass
-            __syncthreads();
-            if (R == 8) {
-#pragma unroll
-                for (int u = 0; u < P / 8; ++u) {
-                    const int id = tl + TPF * u;
-                    const int mp = id % Mj, h = id / Mj;
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) v[u * 8 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
-                    bfly<T, 8>(&v[u * 8]);
-                    if (Mj > 1) {
-#pragma unroll
-                        for (int k = 1; k < 8; ++k) v[u * 8 + k] = cmul(v[u * 8 + k], a.twM[Hprev * mp * k]);
-                    }
-                }
-            } else if (R == 4) {
-#pragma unroll
-                for (int u = 0; u < P / 4; ++u) {
-                    const int id = tl + TPF * u;
-                    const int mp = id % Mj, h = id / Mj;
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) v[u * 4 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
-                    bfly<T, 4>(&v[u * 4]);
-                    if (Mj > 1) {
-#pragma unroll
-                        for (int k = 1; k < 4; ++k) v[u * 4 + k] = cmul(v[u * 4 + k], a.twM[Hprev * mp * k]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < P / 2; ++u) {
-                    const int id = tl + TPF * u;
-                    const int mp = id % Mj, h = id / Mj;
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) v[u * 2 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
-                    bfly<T, 2>(&v[u * 2]);
-                    if (Mj > 1) v[u * 2 + 1] = cmul(v[u * 2 + 1], a.twM[Hprev * mp]);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < P / R; ++u) {
-                const int id = tl + TPF * u;
-                const int mp = id % Mj, h = id / Mj;
-#pragma unroll
-                for (int k = 0; k < R; ++k) buf[lds_pad<S>((h + Hprev * k) * Mj + mp)] = v[u * R + k];
-            }
-        }
-        __syncthreads();
+        lds_fft<T, LOG2M, P>(v, buf, tl, a.twM);
 
         // ---------------- Hermitian post-pass: Z -> X[0..M], |X|, peak ----------------------
         T best = (T)-1;
