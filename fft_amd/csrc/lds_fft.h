@@ -11,14 +11,17 @@
 
 namespace sa {
 
+// Pass plan: with P = 8 points per thread radix-8 passes then one 4 or 2; with P = 16 radix-16 passes
+// then one 8, 4 or 2 (fewer LDS exchanges and barriers for the long transforms).
 template <int LR, int PP = 8> struct FftPlan {
     static constexpr int R = 1 << LR;
-    static constexpr int N8 = LR / 3;
-    static constexpr int REM = LR % 3;
-    static constexpr int NP = N8 + (REM ? 1 : 0);
-    static constexpr int radix(int j) { return j < N8 ? 8 : (1 << REM); }
+    static constexpr int LB = PP == 16 ? 4 : 3;                // log2 of the main radix
+    static constexpr int NB = LR / LB;
+    static constexpr int REM = LR % LB;
+    static constexpr int NP = NB + (REM ? 1 : 0);
+    static constexpr int radix(int j) { return j < NB ? (1 << LB) : (1 << REM); }
     static constexpr int H(int j) { int h = 1; for (int i = 0; i < j; ++i) h *= radix(i); return h; }
-    static constexpr int P = LR >= 3 ? PP : R;                // points per thread (8, or 16 for the largest frames)
+    static constexpr int P = LR >= LB ? PP : R;                // points per thread
     static constexpr int TPF = R / P;                          // threads per transform
 };
 
@@ -33,8 +36,8 @@ template <typename T, int LR> constexpr int lds_fft_elems() {
     return n;
 }
 
-// v[k] *= w^k, k = 1..RJ-1: ONE table load per butterfly, the powers come from a product tree of depth <= 3
-// (a few ulp; keeps the vector-memory path free for the frame data instead of 7 scattered twiddle loads).
+// v[k] *= w^k, k = 1..RJ-1: ONE table load per butterfly, the powers come from a product tree of depth <= 4
+// (a few ulp; keeps the vector-memory path free for the frame data instead of RJ-1 scattered twiddle loads).
 template <typename T, int RJ, typename C>
 __device__ __forceinline__ void apply_twiddle_powers(C* v, C w) {
     if constexpr (RJ == 2) {
@@ -45,67 +48,44 @@ __device__ __forceinline__ void apply_twiddle_powers(C* v, C w) {
     } else {
         const C w2 = cmul(w, w), w3 = cmul(w2, w), w4 = cmul(w2, w2);
         v[1] = cmul(v[1], w); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
-        v[5] = cmul(v[5], cmul(w4, w)); v[6] = cmul(v[6], cmul(w4, w2)); v[7] = cmul(v[7], cmul(w4, w3));
+        const C w5 = cmul(w4, w), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+        v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
+        if constexpr (RJ == 16) {
+            const C w8 = cmul(w4, w4);
+            v[8] = cmul(v[8], w8);
+            v[9] = cmul(v[9], cmul(w8, w));    v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
+            v[12] = cmul(v[12], cmul(w8, w4)); v[13] = cmul(v[13], cmul(w8, w5)); v[14] = cmul(v[14], cmul(w8, w6));
+            v[15] = cmul(v[15], cmul(w8, w7));
+        }
     }
 }
 
-// Input convention: v[u * R0 + n1] = x[n1 * (R / R0) + (tl + TPF * u)],  R0 = first radix, u < P / R0.
-// twR[i] = w_R^i, i < R (global or LDS table).
-template <typename T, int LR, int PP = 8>
-__device__ __forceinline__ void lds_fft(cplx<T>* v, cplx<T>* buf, int tl, const cplx<T>* __restrict__ twR) {
-    using C = cplx<T>;
+// passes J .. NP-1 (J >= 1): LDS -> registers, butterfly, twiddle, registers -> LDS
+template <typename T, int LR, int PP, int J>
+__device__ __forceinline__ void lds_fft_pass(cplx<T>* v, cplx<T>* buf, int tl, const cplx<T>* __restrict__ twR) {
     using PL = FftPlan<LR, PP>;
-    constexpr int R = PL::R, P = PL::P, TPF = PL::TPF;
-    constexpr int S = LdsPadShift<T>::value;
-    {
-        constexpr int R0 = PL::radix(0);
-        constexpr int Mj = R / R0;
+    if constexpr (J < PL::NP) {
+        constexpr int R = PL::R, P = PL::P, TPF = PL::TPF;
+        constexpr int S = LdsPadShift<T>::value;
+        constexpr int Rj = PL::radix(J), Hprev = PL::H(J), Mprev = R / Hprev, Mj = Mprev / Rj;
+        // opaque lane index: the per-pass LDS addresses are re-derived here (a few integer ops) instead of
+        // being hoisted out of the caller's frame loop, where they would pin ~16 VGPRs per pass
+        asm volatile("" : "+v"(tl));
+        // the pass' twiddles are requested BEFORE the barrier so their L2 latency overlaps the wait
+        cplx<T> w[P / Rj];
+        if constexpr (Mj > 1) {
 #pragma unroll
-        for (int u = 0; u < P / R0; ++u) {
-            const int id = tl + TPF * u;
-            bfly<T, R0>(&v[u * R0]);
-            if constexpr (PL::NP > 1) apply_twiddle_powers<T, R0>(&v[u * R0], twR[id]);
-#pragma unroll
-            for (int k = 0; k < R0; ++k) buf[lds_pad<S>(k * Mj + id)] = v[u * R0 + k];
+            for (int u = 0; u < P / Rj; ++u) w[u] = twR[Hprev * ((tl + TPF * u) % Mj)];
         }
-    }
-#pragma unroll
-    for (int j = 1; j < PL::NP; ++j) {
-        const int Rj = PL::radix(j);
-        const int Hprev = PL::H(j);
-        const int Mprev = R / Hprev;
-        const int Mj = Mprev / Rj;
         __syncthreads();
-        if (Rj == 8) {
 #pragma unroll
-            for (int u = 0; u < P / 8; ++u) {
-                const int id = tl + TPF * u;
-                const int mp = id % Mj, h = id / Mj;
+        for (int u = 0; u < P / Rj; ++u) {
+            const int id = tl + TPF * u;
+            const int mp = id % Mj, h = id / Mj;
 #pragma unroll
-                for (int n = 0; n < 8; ++n) v[u * 8 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
-                bfly<T, 8>(&v[u * 8]);
-                if (Mj > 1) apply_twiddle_powers<T, 8>(&v[u * 8], twR[Hprev * mp]);
-            }
-        } else if (Rj == 4) {
-#pragma unroll
-            for (int u = 0; u < P / 4; ++u) {
-                const int id = tl + TPF * u;
-                const int mp = id % Mj, h = id / Mj;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) v[u * 4 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
-                bfly<T, 4>(&v[u * 4]);
-                if (Mj > 1) apply_twiddle_powers<T, 4>(&v[u * 4], twR[Hprev * mp]);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < P / 2; ++u) {
-                const int id = tl + TPF * u;
-                const int mp = id % Mj, h = id / Mj;
-#pragma unroll
-                for (int n = 0; n < 2; ++n) v[u * 2 + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
-                bfly<T, 2>(&v[u * 2]);
-                if (Mj > 1) v[u * 2 + 1] = cmul(v[u * 2 + 1], twR[Hprev * mp]);
-            }
+            for (int n = 0; n < Rj; ++n) v[u * Rj + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
+            bfly<T, Rj>(&v[u * Rj]);
+            if constexpr (Mj > 1) apply_twiddle_powers<T, Rj>(&v[u * Rj], w[u]);
         }
         __syncthreads();
 #pragma unroll
@@ -115,8 +95,32 @@ __device__ __forceinline__ void lds_fft(cplx<T>* v, cplx<T>* buf, int tl, const 
 #pragma unroll
             for (int k = 0; k < Rj; ++k) buf[lds_pad<S>((h + Hprev * k) * Mj + mp)] = v[u * Rj + k];
         }
+        lds_fft_pass<T, LR, PP, J + 1>(v, buf, tl, twR);
     }
-    __syncthreads();
+}
+
+// Input convention: v[u * R0 + n1] = x[n1 * (R / R0) + (tl + TPF * u)],  R0 = first radix, u < P / R0.
+// twR[i] = w_R^i, i < R (global or LDS table).
+// FINAL_SYNC = false leaves out the last __syncthreads(): the caller issues it (after requesting whatever
+// its epilogue needs from global memory) before reading buf.
+template <typename T, int LR, int PP = 8, bool FINAL_SYNC = true>
+__device__ __forceinline__ void lds_fft(cplx<T>* v, cplx<T>* buf, int tl, const cplx<T>* __restrict__ twR) {
+    using PL = FftPlan<LR, PP>;
+    constexpr int R = PL::R, P = PL::P, TPF = PL::TPF;
+    constexpr int S = LdsPadShift<T>::value;
+    constexpr int R0 = PL::radix(0);
+    constexpr int Mj = R / R0;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int u = 0; u < P / R0; ++u) {
+        const int id = tl + TPF * u;
+        bfly<T, R0>(&v[u * R0]);
+        if constexpr (PL::NP > 1) apply_twiddle_powers<T, R0>(&v[u * R0], twR[id]);
+#pragma unroll
+        for (int k = 0; k < R0; ++k) buf[lds_pad<S>(k * Mj + id)] = v[u * R0 + k];
+    }
+    lds_fft_pass<T, LR, PP, 1>(v, buf, tl, twR);
+    if constexpr (FINAL_SYNC) __syncthreads();
 }
 
 }  // namespace sa

@@ -14,19 +14,6 @@
 
 namespace sa {
 
-// ---- compile-time pass plan: radix-8 passes, then one 4 or 2 ---------------------------------
-template <int LOG2M> struct Plan {
-    static constexpr int M = 1 << LOG2M;
-    static constexpr int N8 = LOG2M / 3;
-    static constexpr int REM = LOG2M % 3;            // 0,1,2 -> extra radix 1,2,4
-    static constexpr int NP = N8 + (REM ? 1 : 0);
-    static constexpr int radix(int j) { return j < N8 ? 8 : (1 << REM); }
-    // H_{j} = R_1...R_j (product of the first j radices), M_j = M / H_j
-    static constexpr int H(int j) { int h = 1; for (int i = 0; i < j; ++i) h *= radix(i); return h; }
-};
-
-struct PeakCand { double mag; int bin; };   // only used on the host side
-
 template <typename T> __device__ __forceinline__ bool peak_better(T m, int k, T bm, int bk) {
     return (m > bm) || (m == bm && k < bk);
 }
@@ -50,7 +37,7 @@ template <typename T, int LOG2M, int P /*points per thread*/, int FPW /*frames p
 __global__ void __launch_bounds__((((1 << LOG2M) / P) * FPW))
 rfft_mag_peak_generic(RfftArgs<T> a) {
     using C = cplx<T>;
-    using PL = Plan<LOG2M>;
+    using PL = FftPlan<LOG2M, P>;
     constexpr int M = 1 << LOG2M;
     constexpr int TPF = M / P;                       // threads per frame
     constexpr int S = (sizeof(C) == 8) ? 5 : 4;      // pad granule (elements per LDS bank row)
@@ -74,59 +61,69 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
         C v[P];
 
         // ---------------- global load (+window) into the first pass' registers, FFT through LDS -----
+        // All loads of the frame are issued back to back (no per-element branch: frames past the end of
+        // the batch re-read frame 0 and are discarded at the stores).
         {
             constexpr int R = PL::radix(0);
             constexpr int Mj = M / R;
 #pragma unroll
-            for (int u = 0; u < P / R; ++u) {
-                const int id = tl + TPF * u;
+            for (int u = 0; u < P / R; ++u)
 #pragma unroll
-                for (int n1 = 0; n1 < R; ++n1) {
-                    const int c = n1 * Mj + id;
-                    C z = valid ? *reinterpret_cast<const C*>(xf + 2 * c) : mk<T>(0, 0);
-                    if (a.win) {
-                        const C w = *reinterpret_cast<const C*>(a.win + 2 * c);
-                        z.x *= w.x; z.y *= w.y;
-                    }
-                    v[u * R + n1] = z;
-                }
+                for (int n1 = 0; n1 < R; ++n1)
+                    v[u * R + n1] = *reinterpret_cast<const C*>(xf + 2 * (n1 * Mj + tl + TPF * u));
+            if (a.win) {
+                C w[P];
+#pragma unroll
+                for (int u = 0; u < P / R; ++u)
+#pragma unroll
+                    for (int n1 = 0; n1 < R; ++n1)
+                        w[u * R + n1] = *reinterpret_cast<const C*>(a.win + 2 * (n1 * Mj + tl + TPF * u));
+#pragma unroll
+                for (int i = 0; i < P; ++i) { v[i].x *= w[i].x; v[i].y *= w[i].y; }
             }
         }
-        lds_fft<T, LOG2M, P>(v, buf, tl, a.twM);
+        lds_fft<T, LOG2M, P, false>(v, buf, tl, a.twM);
 
         // ---------------- Hermitian post-pass: Z -> X[0..M], |X|, peak ----------------------
+        // pair q < M/2 gives bins q and M-q; thread 0 adds the self-paired bin M/2.  The w_N^q factors
+        // are requested before the barrier that publishes Z.
+        constexpr int NIT = (M / 2) / TPF;
+        C tn[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tl + TPF * u];
+        __syncthreads();
         T best = (T)-1;
         int best_k = 0x7fffffff;
         const bool excl = (a.flags & 4) != 0;
-        const bool wmag = (a.flags & 1) != 0 && a.mag != nullptr;
+        const bool wmag = (a.flags & 1) != 0 && a.mag != nullptr && valid;
         const bool wdb = (a.flags & 2) != 0;
-        T* mf = wmag ? a.mag + (valid ? frame : 0) * (int64_t)(M + 1) : nullptr;
-        constexpr int NPAIR = M / 2 + 1;             // q = 0 .. M/2
+        T* mf = a.mag + (valid ? frame : 0) * (int64_t)(M + 1);
 #pragma unroll
-        for (int u = 0; u < (NPAIR + TPF - 1) / TPF; ++u) {
+        for (int u = 0; u < NIT; ++u) {
             const int q = tl + TPF * u;
-            if (q < NPAIR) {
-                const C zq = buf[lds_pad<S>(q)];
-                const C zm = buf[lds_pad<S>((M - q) & (M - 1))];
-                // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
-                const C e = mk<T>((T)0.5 * (zq.x + zm.x), (T)0.5 * (zq.y - zm.y));
-                const C d = mk<T>((T)0.5 * (zq.x - zm.x), (T)0.5 * (zq.y + zm.y));
-                const C o = mk<T>(d.y, -d.x);
-                const C wo = cmul(o, a.twN[q]);
-                const C xa = cadd(e, wo);            // X[q]
-                const C xb = csub(e, wo);            // conj(X[M-q])
-                const T ma = sqrt(xa.x * xa.x + xa.y * xa.y);
-                const T mb = sqrt(xb.x * xb.x + xb.y * xb.y);
-                const int ka = q, kb = M - q;
-                if (wmag && valid) {
-                    mf[ka] = wdb ? (T)20 * log10(fmax(ma, a.db_floor)) : ma;
-                    if (kb != ka) mf[kb] = wdb ? (T)20 * log10(fmax(mb, a.db_floor)) : mb;
-                }
-                const bool oka = !(excl && ka == 0);
-                const bool okb = !(excl && kb == M) && kb != ka;
-                if (oka && peak_better(ma, ka, best, best_k)) { best = ma; best_k = ka; }
-                if (okb && peak_better(mb, kb, best, best_k)) { best = mb; best_k = kb; }
+            const C zq = buf[lds_pad<S>(q)];
+            const C zm = buf[lds_pad<S>((M - q) & (M - 1))];
+            // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
+            const C e = mk<T>((T)0.5 * (zq.x + zm.x), (T)0.5 * (zq.y - zm.y));
+            const C d = mk<T>((T)0.5 * (zq.x - zm.x), (T)0.5 * (zq.y + zm.y));
+            const C wo = cmul(mk<T>(d.y, -d.x), tn[u]);
+            const C xa = cadd(e, wo);            // X[q]
+            const C xb = csub(e, wo);            // conj(X[M-q])
+            const T ma = sqrt(xa.x * xa.x + xa.y * xa.y);
+            const T mb = sqrt(xb.x * xb.x + xb.y * xb.y);
+            const int ka = q, kb = M - q;
+            if (wmag) {
+                mf[ka] = wdb ? (T)20 * log10(fmax(ma, a.db_floor)) : ma;
+                mf[kb] = wdb ? (T)20 * log10(fmax(mb, a.db_floor)) : mb;
             }
+            if (!(excl && ka == 0) && peak_better(ma, ka, best, best_k)) { best = ma; best_k = ka; }
+            if (!(excl && kb == M) && peak_better(mb, kb, best, best_k)) { best = mb; best_k = kb; }
+        }
+        if (tl == 0) {                           // bin M/2: X = conj(Z[M/2])
+            const C z = buf[lds_pad<S>(M / 2)];
+            const T m = sqrt(z.x * z.x + z.y * z.y);
+            if (wmag) mf[M / 2] = wdb ? (T)20 * log10(fmax(m, a.db_floor)) : m;
+            if (peak_better(m, M / 2, best, best_k)) { best = m; best_k = M / 2; }
         }
         // reduce (best, best_k) over the TPF threads of this frame
         constexpr int WREDUCE = TPF < 64 ? TPF : 64;

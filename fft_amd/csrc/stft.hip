@@ -25,6 +25,8 @@ template <typename T>
 int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32_t n, int32_t window, double win_param,
                           int32_t flags, T* mag, int32_t* peak_bin, T* peak_mag, hipStream_t st);
 
+constexpr int STFT_PP(int lr) { return lr >= 14 ? 16 : 8; }   // points per thread
+
 struct StftArgs {
     const int16_t* pcm;     // interleaved stereo
     int64_t nframes;        // STFT frames per channel
@@ -38,8 +40,9 @@ struct StftArgs {
 };
 
 template <int LR>
-__global__ void __launch_bounds__(FftPlan<LR>::TPF) stft_stereo_kernel(StftArgs a) {
-    using PL = FftPlan<LR>;
+__global__ void __launch_bounds__((FftPlan<LR, STFT_PP(LR)>::TPF))
+stft_stereo_kernel(StftArgs a) {
+    using PL = FftPlan<LR, STFT_PP(LR)>;
     constexpr int N = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
     constexpr int S = LdsPadShift<float>::value;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -56,17 +59,27 @@ __global__ void __launch_bounds__(FftPlan<LR>::TPF) stft_stereo_kernel(StftArgs 
     for (int64_t f = blockIdx.x; f < a.nframes; f += gridDim.x) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.pcm) + f * a.hop;   // one (L,R) pair per dword
         float2 v[P];
+        {   // all loads of the frame are issued before the first use (no per-element branches)
+            uint32_t raw[P];
+            float w[P];
 #pragma unroll
-        for (int u = 0; u < P / R0; ++u)
+            for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) {
-                const int j = n1 * (N / R0) + tl + TPF * u;
-                const uint32_t lr = src[j];
-                float l = (float)(int16_t)(lr & 0xFFFF) * scale, r = (float)(int16_t)(lr >> 16) * scale;
-                if (a.win) { const float w = a.win[j]; l *= w; r *= w; }
-                v[u * R0 + n1] = mk<float>(l, r);
+                for (int n1 = 0; n1 < R0; ++n1) raw[u * R0 + n1] = src[n1 * (N / R0) + tl + TPF * u];
+            if (a.win) {
+#pragma unroll
+                for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+                    for (int n1 = 0; n1 < R0; ++n1) w[u * R0 + n1] = a.win[n1 * (N / R0) + tl + TPF * u] * scale;
+            } else {
+#pragma unroll
+                for (int i = 0; i < P; ++i) w[i] = scale;
             }
-        lds_fft<float, LR>(v, buf, tl, a.twR);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+                v[i] = mk<float>((float)(int16_t)(raw[i] & 0xFFFF) * w[i], (float)(int16_t)(raw[i] >> 16) * w[i]);
+        }
+        lds_fft<float, LR, STFT_PP(LR)>(v, buf, tl, a.twR);
         // ---- split channels, magnitudes, peaks ------------------------------------------------------
         float bl = -1.f, br = -1.f;
         int kl = 0x7fffffff, kr = 0x7fffffff;
@@ -143,7 +156,7 @@ static void fill_win32(void* host, void* ctx) {
 
 template <int LR>
 static int launch_stereo(const StftArgs& a, hipStream_t st) {
-    constexpr int NW = (FftPlan<LR>::TPF + 63) / 64;
+    constexpr int NW = (FftPlan<LR, STFT_PP(LR)>::TPF + 63) / 64;
     constexpr int lds = lds_fft_elems<float, LR>() * 8 + NW * 16 + 16;
     auto kern = stft_stereo_kernel<LR>;
     static thread_local bool attr_set = false;
@@ -152,7 +165,7 @@ static int launch_stereo(const StftArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int64_t cap = (int64_t)num_cus() * 8;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.nframes < cap ? a.nframes : cap)), dim3(FftPlan<LR>::TPF), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.nframes < cap ? a.nframes : cap)), dim3(FftPlan<LR, STFT_PP(LR)>::TPF), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }

@@ -43,8 +43,8 @@ struct PipeArgs {
 };
 
 template <int LOG2M, int U>
-__global__ void __launch_bounds__(FftPlan<LOG2M>::TPF) synth_pipeline_kernel(PipeArgs a) {
-    using PL = FftPlan<LOG2M>;
+__global__ void __launch_bounds__((FftPlan<LOG2M, 8>::TPF)) synth_pipeline_kernel(PipeArgs a) {
+    using PL = FftPlan<LOG2M, 8>;
     constexpr int M = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
     constexpr int N = 2 * M;
     constexpr int NB = N / U;                          // base points
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(FftPlan<LOG2M>::TPF) synth_pipeline_kernel(Pip
                 const int c = n1 * (M / R0) + tl + TPF * u;
                 v[u * R0 + n1] = mk<float>(sample(2 * c), sample(2 * c + 1));
             }
-        lds_fft<float, LOG2M>(v, buf, tl, a.twM);
+        lds_fft<float, LOG2M, 8>(v, buf, tl, a.twM);
         // ---- 4. Hermitian post-pass, magnitudes, peak ---------------------------------------------------
         float best = -1.f;
         int bk = 0x7fffffff;
@@ -202,7 +202,7 @@ static void fill_brows(void* host, void*) {
 template <int LOG2M, int U>
 static int launch_pipe(const PipeArgs& a, hipStream_t st) {
     constexpr int NBASE = (2 << LOG2M) / U;
-    constexpr int NW = (FftPlan<LOG2M>::TPF + 63) / 64;
+    constexpr int NW = (FftPlan<LOG2M, 8>::TPF + 63) / 64;
     constexpr int lds = lds_fft_elems<float, LOG2M>() * 8 + (U > 1 ? 2 : 1) * NBASE * 4 + NW * 8 + 16;
     auto kern = synth_pipeline_kernel<LOG2M, U>;
     static thread_local bool attr_set = false;
@@ -211,7 +211,7 @@ static int launch_pipe(const PipeArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int64_t cap = (int64_t)num_cus() * 4;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(FftPlan<LOG2M>::TPF), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(FftPlan<LOG2M, 8>::TPF), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
