@@ -60,9 +60,38 @@ __device__ __forceinline__ void apply_twiddle_powers(C* v, C w) {
     }
 }
 
+// lds_pad is additive over disjoint bit fields: pad(a | c) = pad(a) + pad(c) whenever a & c == 0, because
+// (a | c) >> s = (a >> s) | (c >> s).  Every index used below is lane-part | unrolled-part with disjoint
+// fields (lane index < TPF, butterfly leg n * M_j or k * R / R_j, extra butterflies TPF * u), so a pass needs
+// one padded base per access direction and compile-time offsets (ds_read/ds_write immediates).
+
+// Twiddle providers.  Pass j (< NP-1) of thread `id` needs the single factor w_R^(H(j) * (id mod M_j));
+// TwGlobal fetches it from the table each time, TwRegs keeps the NP-1 factors of a thread in registers
+// (they do not depend on the frame, so a kernel looping over frames loads them once).
+template <typename T> struct TwGlobal {
+    const cplx<T>* __restrict__ twR;     // w_R^i, i < R
+    template <int J, int HPREV, int MJ> __device__ __forceinline__ cplx<T> get(int id) const { return twR[HPREV * (id % MJ)]; }
+};
+template <typename T, int LR, int PP = 8> struct TwRegs {
+    using PL = FftPlan<LR, PP>;
+    static_assert(PL::NP == 1 || PL::P == PL::radix(0), "one butterfly per thread in the twiddled passes");
+    cplx<T> w[PL::NP > 1 ? PL::NP - 1 : 1];
+    __device__ __forceinline__ void load(const cplx<T>* __restrict__ twR, int tl) {
+#pragma unroll
+        for (int j = 0; j + 1 < PL::NP; ++j) w[j] = twR[PL::H(j) * (tl % (PL::R / PL::H(j + 1)))];
+    }
+    // opaque copy: the power tree w^2..w^(R-1) is rebuilt at every use (a few multiplies) instead of being
+    // hoisted out of the caller's frame loop, where it would pin 2 (R-1) registers per pass
+    template <int J, int HPREV, int MJ> __device__ __forceinline__ cplx<T> get(int) const {
+        cplx<T> c = w[J];
+        asm volatile("" : "+v"(c.x), "+v"(c.y));
+        return c;
+    }
+};
+
 // passes J .. NP-1 (J >= 1): LDS -> registers, butterfly, twiddle, registers -> LDS
-template <typename T, int LR, int PP, int J>
-__device__ __forceinline__ void lds_fft_pass(cplx<T>* v, cplx<T>* buf, int tl, const cplx<T>* __restrict__ twR) {
+template <typename T, int LR, int PP, int J, typename TW>
+__device__ __forceinline__ void lds_fft_pass(cplx<T>* v, cplx<T>* buf, int tl, const TW& tw) {
     using PL = FftPlan<LR, PP>;
     if constexpr (J < PL::NP) {
         constexpr int R = PL::R, P = PL::P, TPF = PL::TPF;
@@ -75,52 +104,60 @@ __device__ __forceinline__ void lds_fft_pass(cplx<T>* v, cplx<T>* buf, int tl, c
         cplx<T> w[P / Rj];
         if constexpr (Mj > 1) {
 #pragma unroll
-            for (int u = 0; u < P / Rj; ++u) w[u] = twR[Hprev * ((tl + TPF * u) % Mj)];
+            for (int u = 0; u < P / Rj; ++u) w[u] = tw.template get<J, Hprev, Mj>(tl + TPF * u);
         }
+        // Padded addresses are additive over disjoint bit fields of the index (see lds_pad_split below):
+        // one base per pass from the lane index, everything else is a compile-time offset.
+        tl &= TPF - 1;
+        const cplx<T>* rd = buf + lds_pad<S>((tl / Mj) * Mprev + (tl % Mj));
+        cplx<T>* wr = buf + lds_pad<S>(tl);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < P / Rj; ++u) {
-            const int id = tl + TPF * u;
-            const int mp = id % Mj, h = id / Mj;
+            const int cu = ((TPF * u) / Mj) * Mprev + ((TPF * u) % Mj);      // index(0, u, 0): folded at unroll time
 #pragma unroll
-            for (int n = 0; n < Rj; ++n) v[u * Rj + n] = buf[lds_pad<S>(h * Mprev + n * Mj + mp)];
+            for (int n = 0; n < Rj; ++n) v[u * Rj + n] = rd[lds_pad_c<S>(cu + n * Mj)];
             bfly<T, Rj>(&v[u * Rj]);
             if constexpr (Mj > 1) apply_twiddle_powers<T, Rj>(&v[u * Rj], w[u]);
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < P / Rj; ++u) {
-            const int id = tl + TPF * u;
-            const int mp = id % Mj, h = id / Mj;
 #pragma unroll
-            for (int k = 0; k < Rj; ++k) buf[lds_pad<S>((h + Hprev * k) * Mj + mp)] = v[u * Rj + k];
+            for (int k = 0; k < Rj; ++k) wr[lds_pad_c<S>(TPF * u + Hprev * Mj * k)] = v[u * Rj + k];
         }
-        lds_fft_pass<T, LR, PP, J + 1>(v, buf, tl, twR);
+        lds_fft_pass<T, LR, PP, J + 1>(v, buf, tl, tw);
     }
 }
 
 // Input convention: v[u * R0 + n1] = x[n1 * (R / R0) + (tl + TPF * u)],  R0 = first radix, u < P / R0.
-// twR[i] = w_R^i, i < R (global or LDS table).
 // FINAL_SYNC = false leaves out the last __syncthreads(): the caller issues it (after requesting whatever
 // its epilogue needs from global memory) before reading buf.
-template <typename T, int LR, int PP = 8, bool FINAL_SYNC = true>
-__device__ __forceinline__ void lds_fft(cplx<T>* v, cplx<T>* buf, int tl, const cplx<T>* __restrict__ twR) {
+template <typename T, int LR, int PP = 8, bool FINAL_SYNC = true, typename TW>
+__device__ __forceinline__ void lds_fft_tw(cplx<T>* v, cplx<T>* buf, int tl, const TW& tw) {
     using PL = FftPlan<LR, PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF;
     constexpr int S = LdsPadShift<T>::value;
     constexpr int R0 = PL::radix(0);
     constexpr int Mj = R / R0;
     asm volatile("" : "+v"(tl));
+    tl &= TPF - 1;
+    cplx<T>* wr = buf + lds_pad<S>(tl);
 #pragma unroll
     for (int u = 0; u < P / R0; ++u) {
-        const int id = tl + TPF * u;
         bfly<T, R0>(&v[u * R0]);
-        if constexpr (PL::NP > 1) apply_twiddle_powers<T, R0>(&v[u * R0], twR[id]);
+        if constexpr (PL::NP > 1) apply_twiddle_powers<T, R0>(&v[u * R0], tw.template get<0, 1, Mj>(tl + TPF * u));
 #pragma unroll
-        for (int k = 0; k < R0; ++k) buf[lds_pad<S>(k * Mj + id)] = v[u * R0 + k];
+        for (int k = 0; k < R0; ++k) wr[lds_pad_c<S>(k * Mj + TPF * u)] = v[u * R0 + k];
     }
-    lds_fft_pass<T, LR, PP, 1>(v, buf, tl, twR);
+    lds_fft_pass<T, LR, PP, 1>(v, buf, tl, tw);
     if constexpr (FINAL_SYNC) __syncthreads();
+}
+
+// twR[i] = w_R^i, i < R (global table), fetched per pass
+template <typename T, int LR, int PP = 8, bool FINAL_SYNC = true>
+__device__ __forceinline__ void lds_fft(cplx<T>* v, cplx<T>* buf, int tl, const cplx<T>* __restrict__ twR) {
+    lds_fft_tw<T, LR, PP, FINAL_SYNC>(v, buf, tl, TwGlobal<T>{twR});
 }
 
 }  // namespace sa

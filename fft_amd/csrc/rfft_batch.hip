@@ -69,10 +69,11 @@ static bool use_generic_only() {
     return v;
 }
 
-// SA_GENERIC_P (tuning aid): 16 = radix-16 plans (16 points per thread) for n >= 512
-static bool generic_p16() {
-    static const bool v = getenv("SA_GENERIC_P") && atoi(getenv("SA_GENERIC_P")) == 16;
-    return v;
+// Points per thread of the generic kernel: 16 (radix-16 plans) where the sweep in tools/bench_configs.py
+// measured it faster, else 8.  SA_GENERIC_P=8|16 (tuning aid) forces one plan for n >= 512.
+static bool generic_p16(bool dflt) {
+    static const int v = getenv("SA_GENERIC_P") ? atoi(getenv("SA_GENERIC_P")) : 0;
+    return v ? v == 16 : dflt;
 }
 
 template <typename T>
@@ -91,12 +92,12 @@ int dispatch_generic<float>(int log2n, const RfftArgs<float>& a, hipStream_t st)
         case 6: return launch_generic<float, 5, 8>(a, st);
         case 7: return launch_generic<float, 6, 8>(a, st);
         case 8: return launch_generic<float, 7, 8>(a, st);
-        case 9: return generic_p16() ? launch_generic<float, 8, 16>(a, st) : launch_generic<float, 8, 8>(a, st);
-        case 10: return generic_p16() ? launch_generic<float, 9, 16>(a, st) : launch_generic<float, 9, 8>(a, st);
-        case 11: return generic_p16() ? launch_generic<float, 10, 16>(a, st) : launch_generic<float, 10, 8>(a, st);
-        case 12: return generic_p16() ? launch_generic<float, 11, 16>(a, st) : launch_generic<float, 11, 8>(a, st);
-        case 13: return generic_p16() ? launch_generic<float, 12, 16>(a, st) : launch_generic<float, 12, 8>(a, st);
-        case 14: return generic_p16() ? launch_generic<float, 13, 16>(a, st) : launch_generic<float, 13, 8>(a, st);
+        case 9: return generic_p16(true) ? launch_generic<float, 8, 16>(a, st) : launch_generic<float, 8, 8>(a, st);
+        case 10: return generic_p16(true) ? launch_generic<float, 9, 16>(a, st) : launch_generic<float, 9, 8>(a, st);
+        case 11: return generic_p16(true) ? launch_generic<float, 10, 16>(a, st) : launch_generic<float, 10, 8>(a, st);
+        case 12: return generic_p16(false) ? launch_generic<float, 11, 16>(a, st) : launch_generic<float, 11, 8>(a, st);
+        case 13: return generic_p16(false) ? launch_generic<float, 12, 16>(a, st) : launch_generic<float, 12, 8>(a, st);
+        case 14: return generic_p16(true) ? launch_generic<float, 13, 16>(a, st) : launch_generic<float, 13, 8>(a, st);
         case 15: return launch_generic<float, 14, 16>(a, st);
     }
     set_error("rfft f32: n=2^%d unsupported (16 <= n <= 32768, power of two)", log2n);
@@ -111,12 +112,12 @@ int dispatch_generic<double>(int log2n, const RfftArgs<double>& a, hipStream_t s
         case 6: return launch_generic<double, 5, 8>(a, st);
         case 7: return launch_generic<double, 6, 8>(a, st);
         case 8: return launch_generic<double, 7, 8>(a, st);
-        case 9: return generic_p16() ? launch_generic<double, 8, 16>(a, st) : launch_generic<double, 8, 8>(a, st);
-        case 10: return generic_p16() ? launch_generic<double, 9, 16>(a, st) : launch_generic<double, 9, 8>(a, st);
-        case 11: return generic_p16() ? launch_generic<double, 10, 16>(a, st) : launch_generic<double, 10, 8>(a, st);
-        case 12: return generic_p16() ? launch_generic<double, 11, 16>(a, st) : launch_generic<double, 11, 8>(a, st);
-        case 13: return generic_p16() ? launch_generic<double, 12, 16>(a, st) : launch_generic<double, 12, 8>(a, st);
-        case 14: return generic_p16() ? launch_generic<double, 13, 16>(a, st) : launch_generic<double, 13, 8>(a, st);
+        case 9: return generic_p16(false) ? launch_generic<double, 8, 16>(a, st) : launch_generic<double, 8, 8>(a, st);
+        case 10: return generic_p16(false) ? launch_generic<double, 9, 16>(a, st) : launch_generic<double, 9, 8>(a, st);
+        case 11: return generic_p16(false) ? launch_generic<double, 10, 16>(a, st) : launch_generic<double, 10, 8>(a, st);
+        case 12: return generic_p16(false) ? launch_generic<double, 11, 16>(a, st) : launch_generic<double, 11, 8>(a, st);
+        case 13: return generic_p16(false) ? launch_generic<double, 12, 16>(a, st) : launch_generic<double, 12, 8>(a, st);
+        case 14: return generic_p16(true) ? launch_generic<double, 13, 16>(a, st) : launch_generic<double, 13, 8>(a, st);
     }
     set_error("rfft f64: n=2^%d unsupported (16 <= n <= 16384, power of two)", log2n);
     return SA_EUNSUP;

@@ -12,6 +12,7 @@
 // Other channel counts: a de-interleave + convert pass, then the batched rfft kernels with
 //   frame stride = hop.
 // Output layout: mag[channel][frame][nfft/2+1], peak_bin / peak_mag[channel][frame].
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -25,7 +26,7 @@ template <typename T>
 int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32_t n, int32_t window, double win_param,
                           int32_t flags, T* mag, int32_t* peak_bin, T* peak_mag, hipStream_t st);
 
-constexpr int STFT_PP(int lr) { return lr >= 14 ? 16 : 8; }   // points per thread
+constexpr int STFT_PP(int lr) { return lr >= 10 ? 16 : 8; }   // points per thread
 
 struct StftArgs {
     const int16_t* pcm;     // interleaved stereo
@@ -39,10 +40,10 @@ struct StftArgs {
     float* peak_mag;        // [2][nframes]
 };
 
-template <int LR>
-__global__ void __launch_bounds__((FftPlan<LR, STFT_PP(LR)>::TPF))
+template <int LR, int PP>
+__global__ void __launch_bounds__((FftPlan<LR, PP>::TPF))
 stft_stereo_kernel(StftArgs a) {
-    using PL = FftPlan<LR, STFT_PP(LR)>;
+    using PL = FftPlan<LR, PP>;
     constexpr int N = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
     constexpr int S = LdsPadShift<float>::value;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -51,58 +52,82 @@ stft_stereo_kernel(StftArgs a) {
     float* red_m = reinterpret_cast<float*>(buf + lds_fft_elems<float, LR>());
     int* red_k = reinterpret_cast<int*>(red_m + 2 * NW);
     const int tl = threadIdx.x;
-    const float scale = 1.0f / 32768.0f;
     const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
     const bool wdb = a.flags & SA_F_DB;
     const bool excl = a.flags & SA_F_EXCLUDE_DC_NYQ;
     constexpr int NB = N / 2 + 1;
+    // Per-thread constants of the whole launch: every thread handles the same positions of every frame,
+    // so its window samples (pre-scaled by 1/32768) and FFT twiddles live in registers; inside the frame
+    // loop the only global loads are the PCM words, and those of the NEXT frame are in flight while this
+    // frame is transformed.
+    float w[P];
+    if (a.win) {
+#pragma unroll
+        for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; ++n1) w[u * R0 + n1] = a.win[n1 * (N / R0) + TPF * u + tl] * (1.0f / 32768.0f);
+    } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i) w[i] = 1.0f / 32768.0f;
+    }
+    TwRegs<float, LR, PP> tw;
+    tw.load(a.twR, tl);
+    const uint32_t* pcm = reinterpret_cast<const uint32_t*>(a.pcm);   // one (L,R) pair per dword
+    uint32_t raw[P];
+    // Frame loads / spectrum stores go through buffer descriptors built from scalars: one 32-bit lane
+    // offset per access family plus scalar offsets, range-checked by the hardware.
+    auto load_frame = [&](int64_t f, int lane4) {
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(pcm + f * a.hop), 0, N * 4, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; ++n1)
+                raw[u * R0 + n1] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, (n1 * (N / R0) + TPF * u) * 4, 0);
+    };
+    if ((int64_t)blockIdx.x < a.nframes) load_frame(blockIdx.x, tl * 4);
     for (int64_t f = blockIdx.x; f < a.nframes; f += gridDim.x) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.pcm) + f * a.hop;   // one (L,R) pair per dword
+        int tq = tl;                             // opaque per frame: nothing below is hoisted out of the loop
+        asm volatile("" : "+v"(tq));
+        tq &= TPF - 1;
         float2 v[P];
-        {   // all loads of the frame are issued before the first use (no per-element branches)
-            uint32_t raw[P];
-            float w[P];
 #pragma unroll
-            for (int u = 0; u < P / R0; ++u)
-#pragma unroll
-                for (int n1 = 0; n1 < R0; ++n1) raw[u * R0 + n1] = src[n1 * (N / R0) + tl + TPF * u];
-            if (a.win) {
-#pragma unroll
-                for (int u = 0; u < P / R0; ++u)
-#pragma unroll
-                    for (int n1 = 0; n1 < R0; ++n1) w[u * R0 + n1] = a.win[n1 * (N / R0) + tl + TPF * u] * scale;
-            } else {
-#pragma unroll
-                for (int i = 0; i < P; ++i) w[i] = scale;
-            }
-#pragma unroll
-            for (int i = 0; i < P; ++i)
-                v[i] = mk<float>((float)(int16_t)(raw[i] & 0xFFFF) * w[i], (float)(int16_t)(raw[i] >> 16) * w[i]);
-        }
-        lds_fft<float, LR, STFT_PP(LR)>(v, buf, tl, a.twR);
+        for (int i = 0; i < P; ++i)
+            v[i] = mk<float>((float)(int16_t)(raw[i] & 0xFFFF) * w[i], (float)(int16_t)(raw[i] >> 16) * w[i]);
+        load_frame(f + gridDim.x < a.nframes ? f + gridDim.x : f, tq * 4);   // last round re-reads (L2-hot), unused
+        lds_fft_tw<float, LR, PP>(v, buf, tl, tw);
         // ---- split channels, magnitudes, peaks ------------------------------------------------------
+        // pair q < N/2 ... thread 0 adds bin N/2 (rows are NB floats; stores past a row are dropped by
+        // the descriptor's range check, a zero-length descriptor drops them all)
+        asm volatile("" : "+v"(tq));
+        tq &= TPF - 1;
         float bl = -1.f, br = -1.f;
         int kl = 0x7fffffff, kr = 0x7fffffff;
-        float* ml = wmag ? a.mag + f * NB : nullptr;
-        float* mr = wmag ? a.mag + (a.nframes + f) * NB : nullptr;
-#pragma unroll
-        for (int u = 0; u < (NB + TPF - 1) / TPF; ++u) {
-            const int q = tl + TPF * u;                 // ascending per thread: first max kept with '>'
-            if (q < NB) {
-                const float2 zq = buf[lds_pad<S>(q)];
-                const float2 zm = buf[lds_pad<S>((N - q) & (N - 1))];
-                const float2 L = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
-                const float2 Rr = mk<float>(0.5f * (zq.y + zm.y), 0.5f * (zm.x - zq.x));
-                const float mL = sqrtf(L.x * L.x + L.y * L.y), mR = sqrtf(Rr.x * Rr.x + Rr.y * Rr.y);
-                if (wmag) {
-                    ml[q] = wdb ? 20.0f * log10f(fmaxf(mL, SA_DB_FLOOR_F32)) : mL;
-                    mr[q] = wdb ? 20.0f * log10f(fmaxf(mR, SA_DB_FLOOR_F32)) : mR;
-                }
-                if (!(excl && (q == 0 || q == N / 2))) {
-                    if (mL > bl) { bl = mL; kl = q; }
-                    if (mR > br) { br = mR; kr = q; }
-                }
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+            wmag ? a.mag + f * NB : nullptr, 0, wmag ? NB * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+            wmag ? a.mag + (a.nframes + f) * NB : nullptr, 0, wmag ? NB * 4 : 0, 0x00020000);
+        auto emit = [&](int q, int voff, int soff, float2 zq, float2 zm) {
+            const float2 L = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
+            const float2 Rr = mk<float>(0.5f * (zq.y + zm.y), 0.5f * (zm.x - zq.x));
+            const float mL = sqrtf(L.x * L.x + L.y * L.y), mR = sqrtf(Rr.x * Rr.x + Rr.y * Rr.y);
+            const float oL = wdb ? 20.0f * log10f(fmaxf(mL, SA_DB_FLOOR_F32)) : mL;
+            const float oR = wdb ? 20.0f * log10f(fmaxf(mR, SA_DB_FLOOR_F32)) : mR;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oL), rl, voff, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oR), rr, voff, soff, 0);
+            if (!(excl && (q == 0 || q == N / 2))) {
+                if (mL > bl) { bl = mL; kl = q; }   // q ascending per thread: first max kept with '>'
+                if (mR > br) { br = mR; kr = q; }
             }
+        };
+#pragma unroll
+        for (int u = 0; u < (N / 2) / TPF; ++u) {
+            const int q = tq + TPF * u;
+            emit(q, tq * 4, TPF * u * 4, buf[lds_pad<S>(q)], buf[lds_pad<S>((N - q) & (N - 1))]);
+        }
+        if (tq == 0) {
+            const float2 z = buf[lds_pad<S>(N / 2)];
+            emit(N / 2, 0, (N / 2) * 4, z, z);
         }
         constexpr int WRED = TPF < 64 ? TPF : 64;
 #pragma unroll
@@ -154,20 +179,35 @@ static void fill_win32(void* host, void* ctx) {
     for (size_t i = 0; i < w.size(); ++i) o[i] = (float)w[i];
 }
 
-template <int LR>
-static int launch_stereo(const StftArgs& a, hipStream_t st) {
-    constexpr int NW = (FftPlan<LR, STFT_PP(LR)>::TPF + 63) / 64;
+template <int LR, int PP>
+static int launch_stereo_pp(const StftArgs& a, hipStream_t st) {
+    constexpr int NW = (FftPlan<LR, PP>::TPF + 63) / 64;
     constexpr int lds = lds_fft_elems<float, LR>() * 8 + NW * 16 + 16;
-    auto kern = stft_stereo_kernel<LR>;
+    auto kern = stft_stereo_kernel<LR, PP>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const int64_t cap = (int64_t)num_cus() * 8;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.nframes < cap ? a.nframes : cap)), dim3(FftPlan<LR, STFT_PP(LR)>::TPF), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.nframes < cap ? a.nframes : cap)), dim3(FftPlan<LR, PP>::TPF), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
+}
+
+// SA_STFT_PP (tuning aid): points per thread of the stereo kernel (8 or 16)
+static int stft_pp_override() {
+    static const int v = getenv("SA_STFT_PP") ? atoi(getenv("SA_STFT_PP")) : 0;
+    return v;
+}
+
+template <int LR>
+static int launch_stereo(const StftArgs& a, hipStream_t st) {
+    const int pp = stft_pp_override() ? stft_pp_override() : STFT_PP(LR);
+    if constexpr (LR >= 8) {
+        if (pp == 16) return launch_stereo_pp<LR, 16>(a, st);
+    }
+    return launch_stereo_pp<LR, 8>(a, st);
 }
 
 int stft_pcm16_dev(const int16_t* pcm, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop, int32_t window,

@@ -35,9 +35,8 @@ def timeit(fn, iters=5, warm=2):
     return (time.perf_counter() - t0) / iters
 
 
-def bench_c3(log2_samples=30):
+def bench_c3(log2_samples=30, nfft=8192, hop=2048):
     ns = 1 << log2_samples
-    nfft, hop = 8192, 2048
     pcm = torch.randint(-20000, 20000, (ns, 2), dtype=torch.int16, device="cuda")
     nf = (ns - nfft) // hop + 1
     mag = torch.empty((2, nf, nfft // 2 + 1), dtype=torch.float32, device="cuda")
@@ -106,9 +105,32 @@ def bench_c5(log2n):
     return res
 
 
+def bench_rfft(n, dtype, log2_total=30):
+    """Generic batched rfft + peak (mode A) at any power-of-two n: spectra/s and algorithmic GB/s."""
+    es = 4 if dtype == "f32" else 8
+    batch = (1 << log2_total) // n // (es // 4)
+    td = torch.float32 if es == 4 else torch.float64
+    x = torch.randn((batch, n), dtype=td, device="cuda")
+    mag = torch.empty((batch, n // 2 + 1), dtype=td, device="cuda")
+    pb = torch.empty(batch, dtype=torch.int32, device="cuda")
+    pm = torch.empty(batch, dtype=td, device="cuda")
+    fn = lib.sa_rfft_peak_f32_dev if es == 4 else lib.sa_rfft_peak_f64_dev
+    run = lambda: _lib.check(fn(P(x), batch, n, _lib.WIN_HANN, 0.0, _lib.F_WRITE_MAG, P(mag), P(pb), P(pm), CUR()))
+    dt = timeit(run, 5, 2)
+    alg = batch * (n * es + (n // 2 + 1) * es + 4 + es)
+    return {"config": f"rfft {dtype} n={n}", "batch": batch, "ms": dt * 1e3, "spectra_per_s": batch / dt, "alg_GB_per_s": alg / dt / 1e9}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c4", "c5"]
     results = []
+    if "sweep" in which:
+        for dtype in ("f32", "f64"):
+            for lg in range(6, 15):
+                results.append(bench_rfft(1 << lg, dtype)); print(json.dumps(results[-1]), flush=True)
+    if "stft" in which:
+        for lg in range(8, 14):
+            results.append(bench_c3(28, 1 << lg, (1 << lg) // 4)); print(json.dumps(results[-1]), flush=True)
     if "c3" in which:
         results.append(bench_c3(30)); print(json.dumps(results[-1]), flush=True)
     if "c4" in which:
