@@ -26,6 +26,9 @@
 namespace sa {
 
 using Cd = double2;
+#ifndef C2C_PP
+#define C2C_PP 8
+#endif
 
 struct C2cArgs {
     const Cd* in;
@@ -47,8 +50,8 @@ struct C2cArgs {
 
 // ---- strided pass ------------------------------------------------------------------------------
 template <int LR, int B>
-__global__ void __launch_bounds__(FftPlan<LR>::TPF * B) c2c_strided_pass(C2cArgs a) {
-    using PL = FftPlan<LR>;
+__global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pass(C2cArgs a) {
+    using PL = FftPlan<LR, C2C_PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
     constexpr int LDSF = lds_fft_elems<double, LR>();
     constexpr int S = LdsPadShift<double>::value;
@@ -72,7 +75,7 @@ __global__ void __launch_bounds__(FftPlan<LR>::TPF * B) c2c_strided_pass(C2cArgs
                 if (a.conj_in) z.y = -z.y;
                 v[u * R0 + n1] = z;
             }
-        lds_fft<double, LR>(v, buf, tl, a.twR);
+        lds_fft<double, LR, C2C_PP>(v, buf, tl, a.twR);
         // twiddle w_{R S}^{s k} and store, B contiguous columns per k
         constexpr int NT = TPF * B;
 #pragma unroll
@@ -92,8 +95,8 @@ __global__ void __launch_bounds__(FftPlan<LR>::TPF * B) c2c_strided_pass(C2cArgs
 
 // ---- final (contiguous rows) pass ------------------------------------------------------------------
 template <int LR, int B>
-__global__ void __launch_bounds__(FftPlan<LR>::TPF * B) c2c_final_pass(C2cArgs a) {
-    using PL = FftPlan<LR>;
+__global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_final_pass(C2cArgs a) {
+    using PL = FftPlan<LR, C2C_PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
     constexpr int LDSF = lds_fft_elems<double, LR>();
     constexpr int S = LdsPadShift<double>::value;
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(FftPlan<LR>::TPF * B) c2c_final_pass(C2cArgs a
                 if (a.conj_in) z.y = -z.y;
                 v[u * R0 + n1] = z;
             }
-        lds_fft<double, LR>(v, buf, tl, a.twR);
+        lds_fft<double, LR, C2C_PP>(v, buf, tl, a.twR);
         constexpr int NT = TPF * B;
 #pragma unroll
         for (int u = 0; u < (R * B) / NT; ++u) {
@@ -160,7 +163,7 @@ static int launch_strided(C2cArgs a, hipStream_t st) {
     }
     const int64_t ngroups = a.batch * a.A * (a.S / B);
     const int64_t cap = (int64_t)num_cus() * 16;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR>::TPF * B), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR, C2C_PP>::TPF * B), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
@@ -175,7 +178,7 @@ static int launch_final(C2cArgs a, hipStream_t st) {
     }
     const int64_t ngroups = a.batch * (a.A / B);
     const int64_t cap = (int64_t)num_cus() * 16;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR>::TPF * B), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR, C2C_PP>::TPF * B), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }

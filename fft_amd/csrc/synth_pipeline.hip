@@ -10,6 +10,7 @@
 // sides) is frame independent and its entries decay like (2 - sqrt 3)^|i-j| ~ 0.268^|i-j|: the solve
 // becomes a 41-tap stencil in the interior plus an exact table for the first / last 24 rows, both
 // computed once on the host in fp64 (truncation < 1e-11, far below fp32 rounding).
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -42,9 +43,9 @@ struct PipeArgs {
     float* y_out;                 // [batch][n] upsampled time signal, or nullptr
 };
 
-template <int LOG2M, int U>
-__global__ void __launch_bounds__((FftPlan<LOG2M, 8>::TPF)) synth_pipeline_kernel(PipeArgs a) {
-    using PL = FftPlan<LOG2M, 8>;
+template <int LOG2M, int U, int PP>
+__global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kernel(PipeArgs a) {
+    using PL = FftPlan<LOG2M, PP>;
     constexpr int M = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
     constexpr int N = 2 * M;
     constexpr int NB = N / U;                          // base points
@@ -57,16 +58,41 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, 8>::TPF)) synth_pipeline_kerne
     float* red_m = (U > 1) ? sb + NB : sb;              // no derivative array without upsampling
     int* red_k = reinterpret_cast<int*>(red_m + NW);
     const int tl = threadIdx.x;
+    const bool excl = a.flags & SA_F_EXCLUDE_DC_NYQ;
+    const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
+    const bool wdb = a.flags & SA_F_DB;
+    // Launch constants of the thread (it handles the same positions of every frame): window samples,
+    // FFT twiddles and the Hermitian factors w_n^q stay in registers.
+    float2 w[P];
+    if (a.win) {
+#pragma unroll
+        for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; ++n1)
+                w[u * R0 + n1] = reinterpret_cast<const float2*>(a.win)[n1 * (M / R0) + tl + TPF * u];
+    } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i) w[i] = mk<float>(1.f, 1.f);
+    }
+    TwRegs<float, LOG2M, PP> tw;
+    tw.load(a.twM, tl);
+    constexpr int NIT = (M / 2) / TPF;
+    float2 tn[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tl + TPF * u];
 
     for (int64_t f = blockIdx.x; f < a.batch; f += gridDim.x) {
         sa_gen_params p = a.params[f];
         p.N = NB;
+        int tq = tl;                                    // opaque per frame (keeps address math out of the loop-invariant set)
+        asm volatile("" : "+v"(tq));
+        tq &= TPF - 1;
         // ---- 1. synthesis at the base rate (fp64 phase, fp32 sample) ---------------------------------
-        for (int i = tl; i < NB; i += TPF) yb[i] = (float)modulated_sample(p, i);
+        for (int i = tq; i < NB; i += TPF) yb[i] = (float)modulated_sample(p, i);
         __syncthreads();
         // ---- 2. knot derivatives (per knot spacing) ---------------------------------------------------
         if constexpr (U > 1) {
-            for (int i = tl; i < NB; i += TPF) {
+            for (int i = tq; i < NB; i += TPF) {
                 float s = 0.f;
                 if (i < SPL_RB) {
                     const float* r = a.brows + i * SPL_BC;
@@ -85,57 +111,63 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, 8>::TPF)) synth_pipeline_kerne
             __syncthreads();
         }
         // ---- 3. upsample + window straight into the registers of FFT pass 0 ---------------------------
-        auto sample = [&](int j) -> float {               // j-th point of np.linspace(t0, t_last, N)
-            float v;
+        auto sample = [&](unsigned j) -> float {          // j-th point of np.linspace(t0, t_last, N)
             if constexpr (U == 1) {
-                v = yb[j];
+                return yb[j];
             } else {
-                const long long num = (long long)j * (NB - 1);
-                int i = (int)(num / (N - 1));
+                const unsigned num = j * (unsigned)(NB - 1);           // < 2^25
+                unsigned i = num / (unsigned)(N - 1);
                 if (i > NB - 2) i = NB - 2;
-                const float u = (float)(num - (long long)i * (N - 1)) * (1.0f / (float)(N - 1));
+                const float u = (float)(num - i * (unsigned)(N - 1)) * (1.0f / (float)(N - 1));
                 const float y0 = yb[i], y1 = yb[i + 1], s0 = sb[i], s1 = sb[i + 1];
                 const float slope = y1 - y0, tt = s0 + s1 - 2.f * slope;
-                v = ((tt * u + (slope - s0 - tt)) * u + s0) * u + y0;      // scipy PPoly coefficients, dx = 1
+                return ((tt * u + (slope - s0 - tt)) * u + s0) * u + y0;   // scipy PPoly coefficients, dx = 1
             }
-            if (a.y_out) a.y_out[f * N + j] = v;
-            if (a.win) v *= a.win[j];
-            return v;
         };
         float2 v[P];
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
             for (int n1 = 0; n1 < R0; ++n1) {
-                const int c = n1 * (M / R0) + tl + TPF * u;
+                const unsigned c = n1 * (M / R0) + tq + TPF * u;
                 v[u * R0 + n1] = mk<float>(sample(2 * c), sample(2 * c + 1));
             }
-        lds_fft<float, LOG2M, 8>(v, buf, tl, a.twM);
+        if (a.y_out) {
+            float2* yo = reinterpret_cast<float2*>(a.y_out + f * N);
+#pragma unroll
+            for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+                for (int n1 = 0; n1 < R0; ++n1) yo[n1 * (M / R0) + tq + TPF * u] = v[u * R0 + n1];
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) { v[i].x *= w[i].x; v[i].y *= w[i].y; }
+        lds_fft_tw<float, LOG2M, PP>(v, buf, tl, tw);
         // ---- 4. Hermitian post-pass, magnitudes, peak ---------------------------------------------------
+        asm volatile("" : "+v"(tq));
+        tq &= TPF - 1;
         float best = -1.f;
         int bk = 0x7fffffff;
-        const bool excl = a.flags & SA_F_EXCLUDE_DC_NYQ;
-        const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
-        const bool wdb = a.flags & SA_F_DB;
-        float* mf = wmag ? a.mag + f * (M + 1) : nullptr;
-        constexpr int NPAIR = M / 2 + 1;
-        auto consider = [&](float m, int k) {
-            if (wmag) mf[k] = wdb ? 20.f * log10f(fmaxf(m, SA_DB_FLOOR_F32)) : m;
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+            wmag ? a.mag + f * (M + 1) : nullptr, 0, wmag ? (M + 1) * 4 : 0, 0x00020000);   // zero-length: stores dropped
+        auto consider = [&](float m, int k, int voff, int soff) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wdb ? 20.f * log10f(fmaxf(m, SA_DB_FLOOR_F32)) : m), mrs, voff, soff, 0);
             if (excl && (k == 0 || k == M)) return;
             if (m > best || (m == best && k < bk)) { best = m; bk = k; }
         };
 #pragma unroll
-        for (int u = 0; u < (NPAIR + TPF - 1) / TPF; ++u) {
-            const int q = tl + TPF * u;
-            if (q < NPAIR) {
-                const float2 zq = buf[lds_pad<S>(q)], zm = buf[lds_pad<S>((M - q) & (M - 1))];
-                const float2 e = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
-                const float2 d = mk<float>(0.5f * (zq.x - zm.x), 0.5f * (zq.y + zm.y));
-                const float2 wo = cmul(mk<float>(d.y, -d.x), a.twN[q]);
-                const float2 xa = cadd(e, wo), xb = csub(e, wo);
-                consider(sqrtf(xa.x * xa.x + xa.y * xa.y), q);
-                if (M - q != q) consider(sqrtf(xb.x * xb.x + xb.y * xb.y), M - q);
-            }
+        for (int u = 0; u < NIT; ++u) {                 // pair q < M/2 -> bins q and M - q
+            const int q = tq + TPF * u;
+            const float2 zq = buf[lds_pad<S>(q)], zm = buf[lds_pad<S>((M - q) & (M - 1))];
+            const float2 e = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
+            const float2 d = mk<float>(0.5f * (zq.x - zm.x), 0.5f * (zq.y + zm.y));
+            const float2 wo = cmul(mk<float>(d.y, -d.x), tn[u]);
+            const float2 xa = cadd(e, wo), xb = csub(e, wo);
+            consider(sqrtf(xa.x * xa.x + xa.y * xa.y), q, tq * 4, TPF * u * 4);
+            consider(sqrtf(xb.x * xb.x + xb.y * xb.y), M - q, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
+        }
+        if (tq == 0) {                                  // bin M/2: X = conj(Z[M/2])
+            const float2 z = buf[lds_pad<S>(M / 2)];
+            consider(sqrtf(z.x * z.x + z.y * z.y), M / 2, 0, (M / 2) * 4);
         }
         constexpr int WRED = TPF < 64 ? TPF : 64;
 #pragma unroll
@@ -199,21 +231,29 @@ static void fill_brows(void* host, void*) {
     memcpy(host, b.data(), b.size() * 4);
 }
 
-template <int LOG2M, int U>
-static int launch_pipe(const PipeArgs& a, hipStream_t st) {
+template <int LOG2M, int U, int PP>
+static int launch_pipe_pp(const PipeArgs& a, hipStream_t st) {
     constexpr int NBASE = (2 << LOG2M) / U;
-    constexpr int NW = (FftPlan<LOG2M, 8>::TPF + 63) / 64;
+    constexpr int NW = (FftPlan<LOG2M, PP>::TPF + 63) / 64;
     constexpr int lds = lds_fft_elems<float, LOG2M>() * 8 + (U > 1 ? 2 : 1) * NBASE * 4 + NW * 8 + 16;
-    auto kern = synth_pipeline_kernel<LOG2M, U>;
+    auto kern = synth_pipeline_kernel<LOG2M, U, PP>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const int64_t cap = (int64_t)num_cus() * 4;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(FftPlan<LOG2M, 8>::TPF), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(FftPlan<LOG2M, PP>::TPF), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
+}
+
+// SA_PIPE_PP (tuning aid): points per thread of the fused generator kernel (8 or 16)
+template <int LOG2M, int U>
+static int launch_pipe(const PipeArgs& a, hipStream_t st) {
+    static const int pp = getenv("SA_PIPE_PP") ? atoi(getenv("SA_PIPE_PP")) : 16;   // 16: the fp64 generator needs the 256-VGPR budget
+    if (pp == 16) return launch_pipe_pp<LOG2M, U, 16>(a, st);
+    return launch_pipe_pp<LOG2M, U, 8>(a, st);
 }
 
 int synth_analyze_dev(const sa_gen_params* dparams, int64_t batch, int32_t n_base, int32_t upsample, int32_t window,
