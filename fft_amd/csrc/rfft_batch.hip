@@ -93,10 +93,10 @@ int dispatch_generic<float>(int log2n, const RfftArgs<float>& a, hipStream_t st)
         case 7: return launch_generic<float, 6, 8>(a, st);
         case 8: return launch_generic<float, 7, 8>(a, st);
         case 9: return generic_p16(true) ? launch_generic<float, 8, 16>(a, st) : launch_generic<float, 8, 8>(a, st);
-        case 10: return generic_p16(true) ? launch_generic<float, 9, 16>(a, st) : launch_generic<float, 9, 8>(a, st);
+        case 10: return generic_p16(false) ? launch_generic<float, 9, 16>(a, st) : launch_generic<float, 9, 8>(a, st);
         case 11: return generic_p16(true) ? launch_generic<float, 10, 16>(a, st) : launch_generic<float, 10, 8>(a, st);
         case 12: return generic_p16(false) ? launch_generic<float, 11, 16>(a, st) : launch_generic<float, 11, 8>(a, st);
-        case 13: return generic_p16(false) ? launch_generic<float, 12, 16>(a, st) : launch_generic<float, 12, 8>(a, st);
+        case 13: return generic_p16(true) ? launch_generic<float, 12, 16>(a, st) : launch_generic<float, 12, 8>(a, st);
         case 14: return generic_p16(true) ? launch_generic<float, 13, 16>(a, st) : launch_generic<float, 13, 8>(a, st);
         case 15: return launch_generic<float, 14, 16>(a, st);
     }
@@ -112,11 +112,11 @@ int dispatch_generic<double>(int log2n, const RfftArgs<double>& a, hipStream_t s
         case 6: return launch_generic<double, 5, 8>(a, st);
         case 7: return launch_generic<double, 6, 8>(a, st);
         case 8: return launch_generic<double, 7, 8>(a, st);
-        case 9: return generic_p16(false) ? launch_generic<double, 8, 16>(a, st) : launch_generic<double, 8, 8>(a, st);
+        case 9: return generic_p16(true) ? launch_generic<double, 8, 16>(a, st) : launch_generic<double, 8, 8>(a, st);
         case 10: return generic_p16(false) ? launch_generic<double, 9, 16>(a, st) : launch_generic<double, 9, 8>(a, st);
-        case 11: return generic_p16(false) ? launch_generic<double, 10, 16>(a, st) : launch_generic<double, 10, 8>(a, st);
-        case 12: return generic_p16(false) ? launch_generic<double, 11, 16>(a, st) : launch_generic<double, 11, 8>(a, st);
-        case 13: return generic_p16(false) ? launch_generic<double, 12, 16>(a, st) : launch_generic<double, 12, 8>(a, st);
+        case 11: return generic_p16(true) ? launch_generic<double, 10, 16>(a, st) : launch_generic<double, 10, 8>(a, st);
+        case 12: return generic_p16(true) ? launch_generic<double, 11, 16>(a, st) : launch_generic<double, 11, 8>(a, st);
+        case 13: return generic_p16(true) ? launch_generic<double, 12, 16>(a, st) : launch_generic<double, 12, 8>(a, st);
         case 14: return generic_p16(true) ? launch_generic<double, 13, 16>(a, st) : launch_generic<double, 13, 8>(a, st);
     }
     set_error("rfft f64: n=2^%d unsupported (16 <= n <= 16384, power of two)", log2n);

@@ -54,43 +54,71 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
     T* red_mag = reinterpret_cast<T*>(smem + FPW * LDS_PER_FRAME);
     int* red_bin = reinterpret_cast<int*>(red_mag + NWAVES);
 
+    // Launch constants of a thread (same positions in every frame it handles): FFT twiddles always, window
+    // samples and Hermitian factors too when they are cheap to keep (fp32); fp64 reloads them per frame.
+    constexpr bool HOIST = sizeof(T) == 4;
+    constexpr int R0 = PL::radix(0);
+    constexpr int NIT = (M / 2) / TPF;
+    TwRegs<T, LOG2M, P> tw;
+    tw.load(a.twM, tl);
+    C w[HOIST ? P : 1];
+    C tn[NIT];
+    if constexpr (HOIST) {
+        if (a.win) {
+#pragma unroll
+            for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+                for (int n1 = 0; n1 < R0; ++n1)
+                    w[u * R0 + n1] = reinterpret_cast<const C*>(a.win)[n1 * (M / R0) + tl + TPF * u];
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; ++i) w[i] = mk<T>(1, 1);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tl + TPF * u];
+    }
+
     for (int64_t base = (int64_t)blockIdx.x * FPW; base < a.batch; base += (int64_t)gridDim.x * FPW) {
         const int64_t frame = base + g;
         const bool valid = frame < a.batch;
         const T* xf = a.x + (valid ? frame : 0) * a.frame_stride;
         C v[P];
+        int tq = tl;                                     // opaque per frame
+        asm volatile("" : "+v"(tq));
+        tq &= TPF - 1;
 
         // ---------------- global load (+window) into the first pass' registers, FFT through LDS -----
         // All loads of the frame are issued back to back (no per-element branch: frames past the end of
         // the batch re-read frame 0 and are discarded at the stores).
-        {
-            constexpr int R = PL::radix(0);
-            constexpr int Mj = M / R;
 #pragma unroll
-            for (int u = 0; u < P / R; ++u)
+        for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-                for (int n1 = 0; n1 < R; ++n1)
-                    v[u * R + n1] = *reinterpret_cast<const C*>(xf + 2 * (n1 * Mj + tl + TPF * u));
+            for (int n1 = 0; n1 < R0; ++n1)
+                v[u * R0 + n1] = reinterpret_cast<const C*>(xf)[n1 * (M / R0) + tq + TPF * u];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) { v[i].x *= w[i].x; v[i].y *= w[i].y; }
+        } else {
             if (a.win) {
-                C w[P];
+                C wl[P];
 #pragma unroll
-                for (int u = 0; u < P / R; ++u)
+                for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-                    for (int n1 = 0; n1 < R; ++n1)
-                        w[u * R + n1] = *reinterpret_cast<const C*>(a.win + 2 * (n1 * Mj + tl + TPF * u));
+                    for (int n1 = 0; n1 < R0; ++n1)
+                        wl[u * R0 + n1] = reinterpret_cast<const C*>(a.win)[n1 * (M / R0) + tq + TPF * u];
 #pragma unroll
-                for (int i = 0; i < P; ++i) { v[i].x *= w[i].x; v[i].y *= w[i].y; }
+                for (int i = 0; i < P; ++i) { v[i].x *= wl[i].x; v[i].y *= wl[i].y; }
             }
         }
-        lds_fft<T, LOG2M, P, false>(v, buf, tl, a.twM);
+        lds_fft_tw<T, LOG2M, P, false>(v, buf, tl, tw);
 
         // ---------------- Hermitian post-pass: Z -> X[0..M], |X|, peak ----------------------
-        // pair q < M/2 gives bins q and M-q; thread 0 adds the self-paired bin M/2.  The w_N^q factors
-        // are requested before the barrier that publishes Z.
-        constexpr int NIT = (M / 2) / TPF;
-        C tn[NIT];
+        // pair q < M/2 gives bins q and M-q; thread 0 adds the self-paired bin M/2.  Without hoisting the
+        // w_N^q factors are requested before the barrier that publishes Z.
+        if constexpr (!HOIST) {
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tl + TPF * u];
+            for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tq + TPF * u];
+        }
         __syncthreads();
         T best = (T)-1;
         int best_k = 0x7fffffff;
@@ -100,7 +128,7 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
         T* mf = a.mag + (valid ? frame : 0) * (int64_t)(M + 1);
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
-            const int q = tl + TPF * u;
+            const int q = tq + TPF * u;
             const C zq = buf[lds_pad<S>(q)];
             const C zm = buf[lds_pad<S>((M - q) & (M - 1))];
             // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
@@ -119,7 +147,7 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
             if (!(excl && ka == 0) && peak_better(ma, ka, best, best_k)) { best = ma; best_k = ka; }
             if (!(excl && kb == M) && peak_better(mb, kb, best, best_k)) { best = mb; best_k = kb; }
         }
-        if (tl == 0) {                           // bin M/2: X = conj(Z[M/2])
+        if (tq == 0) {                           // bin M/2: X = conj(Z[M/2])
             const C z = buf[lds_pad<S>(M / 2)];
             const T m = sqrt(z.x * z.x + z.y * z.y);
             if (wmag) mf[M / 2] = wdb ? (T)20 * log10(fmax(m, a.db_floor)) : m;
