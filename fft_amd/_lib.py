@@ -53,6 +53,14 @@ PROTOTYPES = {
     "sa_stft_pcm16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "sa_stft_pcm16_dev": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sa_compute_f64": (C.c_int, [_vp, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sa_time_stats_f64": (C.c_int, [_vp, _i64, _i64, _vp]),
+    "sa_time_stats_f32_dev": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "sa_time_stats_f64_dev": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "sa_find_peaks_f64": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _i32, _i32, _vp, _vp]),
+    "sa_find_peaks_f64_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "sa_spectral_metrics_f64": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp]),
+    "sa_spectral_metrics_f32_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),
+    "sa_spectral_metrics_f64_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),
 }
 
 
@@ -61,6 +69,20 @@ class GenParams(C.Structure):
     _fields_ = [("waveform", _i32), ("am_on", _i32), ("fm_on", _i32), ("apply_vpp", _i32), ("N", _i64),
                 ("duration", _dbl), ("Fc", _dbl), ("Fs", _dbl), ("Fm", _dbl), ("am_depth", _dbl),
                 ("fm_dev", _dbl), ("vpp_half", _dbl), ("seed", _u64)]
+
+
+class TimeStats(C.Structure):
+    """struct sa_time_stats (include/specengine.h)."""
+    _fields_ = [("min", _dbl), ("max", _dbl), ("mean", _dbl), ("mean_sq", _dbl), ("max_abs", _dbl),
+                ("m2", _dbl), ("m3", _dbl), ("m4", _dbl), ("zc_count", _i64), ("zc_first", _i64),
+                ("zc_last", _i64), ("above_mid", _i64), ("argmax", _i64), ("argmin", _i64)]
+
+
+class SpecMetrics(C.Structure):
+    """struct sa_spec_metrics (include/specengine.h)."""
+    _fields_ = [("fund_amp", _dbl), ("harmonic_power", _dbl), ("max_spur", _dbl), ("noise_power", _dbl),
+                ("total_power", _dbl), ("sideband_amp", _dbl), ("fund_bin", _i32), ("harm_lo_bin", _i32),
+                ("n_peaks", _i32), ("top_peak_bin", _i32), ("bw_lo_bin", _i32), ("bw_hi_bin", _i32)]
 
 
 def _share_hip_runtime_with_torch():

@@ -1,0 +1,495 @@
+// metrics.hip — derived per-frame metrics either side of the FFT:
+//
+//   time_stats        Vpp / RMS / mean / crest / zero crossings / duty / kurtosis / skew inputs
+//                     (reference main.py:989-1024 `_calculate_time_analysis`, 1552-1617 panel)
+//   find_peaks        scipy.signal.find_peaks(x, height=, distance=) as the reference calls it
+//                     (main.py:1034, 1639; scipy/signal/_peak_finding.py:729, _peak_finding_utils.pyx)
+//   spectral_metrics  fundamental, harmonic peaks, THD, noise, SNR, SFDR, -3 dB bandwidth, sideband level
+//                     of the positive-frequency half spectrum (main.py:1619-1735 panel)
+//
+// One 256-thread workgroup per frame / row, any length; everything is accumulated in fp64 (the reference
+// computes in fp64), the second pass of a frame re-reads it from L2.  Outputs are a few scalars per
+// frame, so HBM traffic stays one read of the input.
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "runtime.h"
+
+namespace sa {
+
+constexpr int MT = 256;              // threads per workgroup
+constexpr int MW = MT / 64;          // waves per workgroup
+
+// ---- block reductions (all threads call; result valid in every thread) ---------------------------------
+template <typename V, typename F>
+__device__ __forceinline__ V block_reduce(V v, F op, V* lds /*[MW]*/) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off));
+    __syncthreads();                                   // lds may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    V r = lds[0];
+#pragma unroll
+    for (int w = 1; w < MW; ++w) r = op(r, lds[w]);
+    return r;
+}
+struct ValIdx { double v; long long i; };
+__device__ __forceinline__ ValIdx shfl_xor_vi(ValIdx a, int off) {
+    ValIdx r;
+    r.v = __shfl_xor(a.v, off);
+    r.i = __shfl_xor(a.i, off);
+    return r;
+}
+template <typename F>
+__device__ __forceinline__ ValIdx block_reduce_vi(ValIdx v, F better /*(a,b): a wins over b*/, ValIdx* lds) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const ValIdx o = shfl_xor_vi(v, off);
+        if (better(o, v)) v = o;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    ValIdx r = lds[0];
+#pragma unroll
+    for (int w = 1; w < MW; ++w)
+        if (better(lds[w], r)) r = lds[w];
+    return r;
+}
+__device__ __forceinline__ bool vi_max_first(const ValIdx& a, const ValIdx& b) { return a.v > b.v || (a.v == b.v && a.i < b.i); }
+__device__ __forceinline__ bool vi_min_first(const ValIdx& a, const ValIdx& b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
+__device__ __forceinline__ bool vi_max_last(const ValIdx& a, const ValIdx& b) { return a.v > b.v || (a.v == b.v && a.i > b.i); }
+
+struct SumD { __device__ double operator()(double a, double b) const { return a + b; } };
+struct SumL { __device__ long long operator()(long long a, long long b) const { return a + b; } };
+struct MinL { __device__ long long operator()(long long a, long long b) const { return a < b ? a : b; } };
+struct MaxL { __device__ long long operator()(long long a, long long b) const { return a > b ? a : b; } };
+struct MaxD { __device__ double operator()(double a, double b) const { return a > b ? a : b; } };
+
+// ---- time-domain statistics ------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(MT) time_stats_kernel(const T* __restrict__ y, int64_t batch, int64_t n, int64_t stride,
+                                                        sa_time_stats* __restrict__ out) {
+    __shared__ double ld[MW];
+    __shared__ long long ll[MW];
+    __shared__ ValIdx lv[MW];
+    for (int64_t f = blockIdx.x; f < batch; f += gridDim.x) {
+        const T* x = y + f * stride;
+        // pass 1: sums, extrema (first index), sign changes  (np.diff(np.sign(y)) != 0 at i, main.py:1006)
+        double s1 = 0, s2 = 0, mabs = 0;
+        ValIdx mx{-DBL_MAX, 0}, mn{DBL_MAX, 0};
+        long long zc = 0, zf = INT64_MAX, zl = -1;
+        for (int64_t i = threadIdx.x; i < n; i += MT) {
+            const double v = (double)x[i];
+            s1 += v; s2 += v * v;
+            mabs = fmax(mabs, fabs(v));
+            if (v > mx.v) { mx.v = v; mx.i = i; }
+            if (v < mn.v) { mn.v = v; mn.i = i; }
+            if (i + 1 < n) {
+                const double u = (double)x[i + 1];
+                const int sv = (v > 0) - (v < 0), su = (u > 0) - (u < 0);
+                if (sv != su) { ++zc; if (i < zf) zf = i; zl = i; }
+            }
+        }
+        s1 = block_reduce(s1, SumD(), ld);
+        s2 = block_reduce(s2, SumD(), ld);
+        mabs = block_reduce(mabs, MaxD(), ld);
+        mx = block_reduce_vi(mx, vi_max_first, lv);
+        mn = block_reduce_vi(mn, vi_min_first, lv);
+        zc = block_reduce(zc, SumL(), ll);
+        zf = block_reduce(zf, MinL(), ll);
+        zl = block_reduce(zl, MaxL(), ll);
+        const double mean = s1 / (double)n;
+        const double mid = (mx.v + mn.v) / 2;           // duty threshold, main.py:1592
+        // pass 2: central moments about the mean (scipy.stats moment(), biased) and samples above mid level
+        double c2 = 0, c3 = 0, c4 = 0;
+        long long above = 0;
+        for (int64_t i = threadIdx.x; i < n; i += MT) {
+            const double v = (double)x[i];
+            const double d = v - mean, d2 = d * d;
+            c2 += d2; c3 += d2 * d; c4 += d2 * d2;
+            above += v > mid;
+        }
+        c2 = block_reduce(c2, SumD(), ld);
+        c3 = block_reduce(c3, SumD(), ld);
+        c4 = block_reduce(c4, SumD(), ld);
+        above = block_reduce(above, SumL(), ll);
+        if (threadIdx.x == 0) {
+            sa_time_stats r;
+            r.min = mn.v; r.max = mx.v; r.mean = mean; r.mean_sq = s2 / (double)n; r.max_abs = mabs;
+            r.m2 = c2 / (double)n; r.m3 = c3 / (double)n; r.m4 = c4 / (double)n;
+            r.zc_count = zc; r.zc_first = zc ? zf : -1; r.zc_last = zl;
+            r.above_mid = above; r.argmax = mx.i; r.argmin = mn.i;
+            out[f] = r;
+        }
+    }
+}
+
+// ---- find_peaks ---------------------------------------------------------------------------------------------
+// scipy semantics: strict rise into a (possibly flat) top, strict fall after it, the middle sample of a
+// plateau is the peak, the first and last samples are never peaks (_local_maxima_1d); then
+// x[peak] >= height; then, for distance > 1, peaks closer than `distance` samples to a higher peak are
+// dropped in order of decreasing height (_select_by_peak_distance; equal heights: the later peak wins, as
+// with a stable argsort walked from the end).  Returns the peaks in ascending index order.
+//
+// Returns true when sample i (lo < i < hi) starts a peak's top; *mid receives the peak index.
+template <typename T>
+__device__ __forceinline__ bool local_max_at(const T* x, int64_t i, int64_t hi /*last index of the row*/, int64_t* mid) {
+    const T v = x[i];
+    if (!(x[i - 1] < v)) return false;
+    int64_t j = i + 1;
+    while (j < hi && x[j] == v) ++j;
+    if (!(x[j] < v)) return false;
+    *mid = (i + (j - 1)) / 2;
+    return true;
+}
+
+// Ordered compaction of per-thread flags over chunks of MT candidates.
+__device__ __forceinline__ int block_excl_scan(int flag, int* total, int* lds /*[MW + 1]*/) {
+    const unsigned long long b = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int within = __popcll(b & ((1ull << lane) - 1));
+    __syncthreads();
+    if (lane == 0) lds[wave] = __popcll(b);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MW; ++w) {
+        if (w < wave) base += lds[w];
+        tot += lds[w];
+    }
+    *total = tot;
+    return base + within;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(MT) find_peaks_kernel(const T* __restrict__ xall, int64_t batch, int64_t n, double height_abs,
+                                                        double height_rel, int32_t distance, int32_t max_peaks,
+                                                        int32_t* idx_all, int32_t* count_all, uint8_t* state_all) {
+    __shared__ double ld[MW];
+    __shared__ int li[MW + 1];
+    __shared__ int s_any;
+    for (int64_t row = blockIdx.x; row < batch; row += gridDim.x) {
+        const T* x = xall + row * n;
+        int32_t* idx = idx_all + row * (int64_t)max_peaks;
+        uint8_t* state = state_all + row * (int64_t)max_peaks;
+        double height = height_abs;
+        if (height_rel > 0) {
+            double m = -DBL_MAX;
+            for (int64_t i = threadIdx.x; i < n; i += MT) m = fmax(m, (double)x[i]);
+            height = block_reduce(m, MaxD(), ld) * height_rel;
+        }
+        // 1. candidates (local maxima above height), ascending
+        int cnt = 0;
+        bool overflow = false;
+        for (int64_t c0 = 1; c0 < n - 1; c0 += MT) {
+            const int64_t i = c0 + threadIdx.x;
+            int64_t mid = 0;
+            int flag = 0;
+            if (i < n - 1 && local_max_at(x, i, n - 1, &mid) && (double)x[mid] >= height) flag = 1;
+            int tot;
+            const int pos = block_excl_scan(flag, &tot, li);
+            if (flag) {
+                if (cnt + pos < max_peaks) { idx[cnt + pos] = (int32_t)mid; state[cnt + pos] = 0; }
+                else overflow = true;
+            }
+            cnt += tot;
+        }
+        if (cnt > max_peaks) {                          // report the need, keep nothing
+            if (threadIdx.x == 0) count_all[row] = -cnt;
+            __syncthreads();
+            continue;
+        }
+        (void)overflow;
+        __syncthreads();
+        // 2. distance suppression: rounds of "locally highest undecided peak is kept, its neighbours go"
+        if (distance > 1 && cnt > 1) {
+            auto higher = [&](int a, int b) {           // a has priority over b
+                const T va = x[idx[a]], vb = x[idx[b]];
+                return va > vb || (va == vb && a > b);
+            };
+            for (;;) {
+                if (threadIdx.x == 0) s_any = 0;
+                __syncthreads();
+                // phase A: undecided (0) -> tentatively kept (3) if no undecided neighbour within distance outranks it
+                for (int c = threadIdx.x; c < cnt; c += MT) {
+                    if (state[c] != 0) continue;
+                    bool top = true;
+                    // (a neighbour already marked 3 in this phase was undecided when the phase began)
+                    for (int k = c - 1; k >= 0 && idx[c] - idx[k] < distance && top; --k)
+                        if ((state[k] == 0 || state[k] == 3) && higher(k, c)) top = false;
+                    for (int k = c + 1; k < cnt && idx[k] - idx[c] < distance && top; ++k)
+                        if ((state[k] == 0 || state[k] == 3) && higher(k, c)) top = false;
+                    if (top) state[c] = 3;
+                }
+                __syncthreads();
+                // phase B: tentatively kept -> kept (1); undecided neighbours of a kept peak -> removed (2)
+                for (int c = threadIdx.x; c < cnt; c += MT) {
+                    if (state[c] != 0) continue;
+                    bool gone = false;
+                    for (int k = c - 1; k >= 0 && idx[c] - idx[k] < distance && !gone; --k) gone = state[k] == 3;
+                    for (int k = c + 1; k < cnt && idx[k] - idx[c] < distance && !gone; ++k) gone = state[k] == 3;
+                    if (gone) state[c] = 2;
+                    else s_any = 1;                      // still undecided: another round
+                }
+                __syncthreads();
+                for (int c = threadIdx.x; c < cnt; c += MT)
+                    if (state[c] == 3) state[c] = 1;
+                __syncthreads();
+                if (!s_any) break;
+            }
+            // 3. ordered compaction of the kept peaks (write position never passes the read position)
+            int kept = 0;
+            for (int c0 = 0; c0 < cnt; c0 += MT) {
+                const int c = c0 + threadIdx.x;
+                const int flag = c < cnt && state[c] == 1;
+                const int32_t v = c < cnt ? idx[c] : 0;
+                int tot;
+                const int pos = block_excl_scan(flag, &tot, li);
+                if (flag) idx[kept + pos] = v;
+                kept += tot;
+            }
+            cnt = kept;
+        }
+        if (threadIdx.x == 0) count_all[row] = cnt;
+        __syncthreads();
+    }
+}
+
+// ---- spectral metrics of the positive-frequency half spectrum (panel variant, main.py:1619-1735) ------------
+// mag row = bins 0 .. n/2 of a length-n frame; positive bins are 1..K, K = (n-1)/2 (the f > 0 mask, :1622;
+// for even n the Nyquist bin sits at -Fs/2 in fftfreq and is not positive).  f_k = k * freq_step, the
+// value scipy.fft.fftfreq produces (k * (1/(n d))), so every frequency comparison below is the reference's.
+template <typename T>
+__global__ void __launch_bounds__(MT) spectral_metrics_kernel(const T* __restrict__ mag_all, int64_t batch, int64_t n,
+                                                              int64_t row_stride, double freq_step, double side_hz,
+                                                              sa_spec_metrics* __restrict__ out) {
+    __shared__ double ld[MW];
+    __shared__ long long ll[MW];
+    __shared__ ValIdx lv[MW];
+    const int64_t K = (n - 1) / 2;
+    for (int64_t row = blockIdx.x; row < batch; row += gridDim.x) {
+        const T* m = mag_all + row * row_stride;
+        sa_spec_metrics r;
+        r.fund_bin = -1; r.harm_lo_bin = -1; r.n_peaks = 0; r.top_peak_bin = -1; r.bw_lo_bin = -1; r.bw_hi_bin = -1;
+        r.fund_amp = 0; r.harmonic_power = 0; r.max_spur = 0; r.noise_power = 0; r.total_power = 0; r.sideband_amp = 0;
+        // two-sided power of the whole spectrum: |Y0|^2 + 2 sum_{1..K} + (even n) |Y_{n/2}|^2   (np.sum(Y**2), :1043)
+        double tp = 0;
+        ValIdx fx{-DBL_MAX, 0};
+        for (int64_t k = 1 + threadIdx.x; k <= K; k += MT) {
+            const double v = (double)m[k];
+            tp += 2 * v * v;
+            if (v > fx.v) { fx.v = v; fx.i = k; }
+        }
+        tp = block_reduce(tp, SumD(), ld);
+        fx = block_reduce_vi(fx, vi_max_first, lv);           // np.argmax(Y_positive): first maximum (:1627)
+        if (n >= 1) tp += (double)m[0] * (double)m[0];
+        if (n >= 2 && n % 2 == 0) tp += (double)m[n / 2] * (double)m[n / 2];
+        r.total_power = tp;
+        if (K >= 1) {
+            const int64_t k0 = fx.i;
+            const double A = fx.v, f0 = (double)k0 * freq_step;
+            r.fund_bin = (int32_t)k0; r.fund_amp = A;
+            // harmonic mask (f > 0.9 f0) & (f < f_positive[-1])  (:1634): bins k_lo .. K-1
+            const double lim = f0 * 0.9;
+            long long klo = INT64_MAX;
+            for (int64_t k = 1 + threadIdx.x; k <= K; k += MT)
+                if ((double)k * freq_step > lim) { klo = k; break; }     // first k of this thread's stride that passes
+            klo = block_reduce(klo, MinL(), ll);
+            if (klo > K) klo = K;                                        // empty mask
+            const int64_t khi = K - 1;                                   // last bin inside the mask
+            r.harm_lo_bin = (int32_t)klo;
+            // peaks of harmonic_amps = m[klo..khi] above 0.05 A (:1639), highest one (:1640, 1680, 1731)
+            const double height = A * 0.05;
+            double hp = 0;
+            long long np_ = 0;
+            ValIdx top{-DBL_MAX, -1};
+            for (int64_t i = klo + 1 + threadIdx.x; i < khi; i += MT) {
+                int64_t mid;
+                if (local_max_at(m, i, khi, &mid) && (double)m[mid] >= height) {
+                    const double v = (double)m[mid];
+                    hp += v * v; ++np_;
+                    if (v > top.v || (v == top.v && mid > top.i)) { top.v = v; top.i = mid; }
+                }
+            }
+            hp = block_reduce(hp, SumD(), ld);
+            np_ = block_reduce(np_, SumL(), ll);
+            top = block_reduce_vi(top, vi_max_last, lv);
+            r.harmonic_power = hp; r.n_peaks = (int32_t)np_;
+            if (np_ > 0) { r.max_spur = top.v; r.top_peak_bin = (int32_t)top.i; }
+            // noise: positive bins outside the harmonic mask (:1664-1665), -3 dB band (:1691-1696), sidebands (:1717-1718)
+            const double half = A / sqrt(2.0);
+            double noise = 0, side = -DBL_MAX;
+            long long blo = INT64_MAX, bhi = -1;
+            for (int64_t k = 1 + threadIdx.x; k <= K; k += MT) {
+                const double v = (double)m[k], fk = (double)k * freq_step;
+                if (k < klo || k > khi) noise += v * v;
+                if (v >= half) { if (k < blo) blo = k; bhi = k; }
+                if (fk > f0 - side_hz && fk < f0 + side_hz) side = fmax(side, v);
+            }
+            noise = block_reduce(noise, SumD(), ld);
+            side = block_reduce(side, MaxD(), ld);
+            blo = block_reduce(blo, MinL(), ll);
+            bhi = block_reduce(bhi, MaxL(), ll);
+            r.noise_power = noise; r.sideband_amp = side;
+            if (bhi >= 0) { r.bw_lo_bin = (int32_t)blo; r.bw_hi_bin = (int32_t)bhi; }
+        }
+        if (threadIdx.x == 0) out[row] = r;
+        __syncthreads();
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------
+static unsigned grid_for(int64_t batch) {
+    const int64_t cap = (int64_t)num_cus() * 8;
+    return (unsigned)(batch < cap ? (batch < 1 ? 1 : batch) : cap);
+}
+
+template <typename T>
+static int time_stats_dev(const T* y, int64_t batch, int64_t n, int64_t stride, sa_time_stats* out, hipStream_t st) {
+    SA_TRY(ensure_init());
+    if (batch < 0 || n < 1) { set_error("time_stats: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
+    if (batch == 0) return SA_OK;
+    if (!y || !out) { set_error("time_stats: NULL buffer"); return SA_EINVAL; }
+    hipLaunchKernelGGL(time_stats_kernel<T>, dim3(grid_for(batch)), dim3(MT), 0, st, y, batch, n, stride, out);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+template <typename T>
+static int spectral_metrics_dev(const T* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
+                                sa_spec_metrics* out, hipStream_t st) {
+    SA_TRY(ensure_init());
+    if (batch < 0 || n < 1) { set_error("spectral_metrics: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
+    if (batch == 0) return SA_OK;
+    if (!mag || !out) { set_error("spectral_metrics: NULL buffer"); return SA_EINVAL; }
+    hipLaunchKernelGGL(spectral_metrics_kernel<T>, dim3(grid_for(batch)), dim3(MT), 0, st, mag, batch, n, n / 2 + 1, freq_step,
+                       side_hz, out);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+static int find_peaks_dev(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel, int32_t distance,
+                          int32_t max_peaks, int32_t* idx, int32_t* count, uint8_t* state, hipStream_t st) {
+    SA_TRY(ensure_init());
+    if (batch < 0 || n < 1 || max_peaks < 1 || distance < 1) {
+        set_error("find_peaks: need batch >= 0, n >= 1, max_peaks >= 1, distance >= 1");
+        return SA_EINVAL;
+    }
+    if (n > INT32_MAX) { set_error("find_peaks: rows longer than 2^31-1 samples are not supported"); return SA_EUNSUP; }
+    if (batch == 0) return SA_OK;
+    if (!x || !idx || !count || !state) { set_error("find_peaks: NULL buffer"); return SA_EINVAL; }
+    hipLaunchKernelGGL(find_peaks_kernel<double>, dim3(grid_for(batch)), dim3(MT), 0, st, x, batch, n, height_abs, height_rel,
+                       distance, max_peaks, idx, count, state);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+// RAII device scratch for the host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { p = nullptr; set_error("hipMalloc of %zu bytes failed", bytes); return SA_ENOMEM; }
+        return SA_OK;
+    }
+};
+
+}  // namespace sa
+
+extern "C" {
+
+int sa_time_stats_f32_dev(const float* y, int64_t batch, int64_t n, int64_t frame_stride, sa_time_stats* out, void* stream) {
+    SA_TRY(sa::ensure_init());
+    return sa::time_stats_dev<float>(y, batch, n, frame_stride, out, stream ? (hipStream_t)stream : sa::thread_stream());
+}
+int sa_time_stats_f64_dev(const double* y, int64_t batch, int64_t n, int64_t frame_stride, sa_time_stats* out, void* stream) {
+    SA_TRY(sa::ensure_init());
+    return sa::time_stats_dev<double>(y, batch, n, frame_stride, out, stream ? (hipStream_t)stream : sa::thread_stream());
+}
+int sa_time_stats_f64(const double* y, int64_t batch, int64_t n, sa_time_stats* out) {
+    using namespace sa;
+    SA_TRY(ensure_init());
+    if (batch < 0 || n < 1) { set_error("time_stats: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
+    if (batch == 0) return SA_OK;
+    if (!y || !out) { set_error("time_stats: NULL buffer"); return SA_EINVAL; }
+    hipStream_t st = thread_stream();
+    DevBuf dy, dout;
+    SA_TRY(dy.alloc((size_t)batch * n * 8));
+    SA_TRY(dout.alloc((size_t)batch * sizeof(sa_time_stats)));
+    SA_HIP(hipMemcpyAsync(dy.p, y, (size_t)batch * n * 8, hipMemcpyHostToDevice, st));
+    SA_TRY(time_stats_dev<double>(static_cast<const double*>(dy.p), batch, n, n, static_cast<sa_time_stats*>(dout.p), st));
+    SA_HIP(hipMemcpyAsync(out, dout.p, (size_t)batch * sizeof(sa_time_stats), hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    return SA_OK;
+}
+
+int sa_find_peaks_f64_dev(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel, int32_t distance,
+                          int32_t max_peaks, int32_t* idx, int32_t* count, uint8_t* work, void* stream) {
+    SA_TRY(sa::ensure_init());
+    return sa::find_peaks_dev(x, batch, n, height_abs, height_rel, distance, max_peaks, idx, count, work,
+                              stream ? (hipStream_t)stream : sa::thread_stream());
+}
+int sa_find_peaks_f64(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel, int32_t distance,
+                      int32_t max_peaks, int32_t* idx, int32_t* count) {
+    using namespace sa;
+    SA_TRY(ensure_init());
+    if (batch < 0 || n < 1 || max_peaks < 1 || distance < 1) {
+        set_error("find_peaks: need batch >= 0, n >= 1, max_peaks >= 1, distance >= 1");
+        return SA_EINVAL;
+    }
+    if (batch == 0) return SA_OK;
+    if (!x || !idx || !count) { set_error("find_peaks: NULL buffer"); return SA_EINVAL; }
+    hipStream_t st = thread_stream();
+    DevBuf dx, di, dc, ds;
+    SA_TRY(dx.alloc((size_t)batch * n * 8));
+    SA_TRY(di.alloc((size_t)batch * max_peaks * 4));
+    SA_TRY(dc.alloc((size_t)batch * 4));
+    SA_TRY(ds.alloc((size_t)batch * max_peaks));
+    SA_HIP(hipMemcpyAsync(dx.p, x, (size_t)batch * n * 8, hipMemcpyHostToDevice, st));
+    SA_TRY(find_peaks_dev(static_cast<const double*>(dx.p), batch, n, height_abs, height_rel, distance, max_peaks,
+                          static_cast<int32_t*>(di.p), static_cast<int32_t*>(dc.p), static_cast<uint8_t*>(ds.p), st));
+    SA_HIP(hipMemcpyAsync(idx, di.p, (size_t)batch * max_peaks * 4, hipMemcpyDeviceToHost, st));
+    SA_HIP(hipMemcpyAsync(count, dc.p, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    for (int64_t b = 0; b < batch; ++b)
+        if (count[b] < 0) {
+            set_error("find_peaks: row %lld has %d peaks, max_peaks=%d is too small", (long long)b, -count[b], max_peaks);
+            return SA_EINVAL;
+        }
+    return SA_OK;
+}
+
+int sa_spectral_metrics_f32_dev(const float* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
+                                sa_spec_metrics* out, void* stream) {
+    SA_TRY(sa::ensure_init());
+    return sa::spectral_metrics_dev<float>(mag, batch, n, freq_step, side_hz, out, stream ? (hipStream_t)stream : sa::thread_stream());
+}
+int sa_spectral_metrics_f64_dev(const double* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
+                                sa_spec_metrics* out, void* stream) {
+    SA_TRY(sa::ensure_init());
+    return sa::spectral_metrics_dev<double>(mag, batch, n, freq_step, side_hz, out, stream ? (hipStream_t)stream : sa::thread_stream());
+}
+int sa_spectral_metrics_f64(const double* mag, int64_t batch, int64_t n, double freq_step, double side_hz, sa_spec_metrics* out) {
+    using namespace sa;
+    SA_TRY(ensure_init());
+    if (batch < 0 || n < 1) { set_error("spectral_metrics: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
+    if (batch == 0) return SA_OK;
+    if (!mag || !out) { set_error("spectral_metrics: NULL buffer"); return SA_EINVAL; }
+    hipStream_t st = thread_stream();
+    const size_t nb = (size_t)(n / 2 + 1);
+    DevBuf dm, dout;
+    SA_TRY(dm.alloc((size_t)batch * nb * 8));
+    SA_TRY(dout.alloc((size_t)batch * sizeof(sa_spec_metrics)));
+    SA_HIP(hipMemcpyAsync(dm.p, mag, (size_t)batch * nb * 8, hipMemcpyHostToDevice, st));
+    SA_TRY(spectral_metrics_dev<double>(static_cast<const double*>(dm.p), batch, n, freq_step, side_hz,
+                                        static_cast<sa_spec_metrics*>(dout.p), st));
+    SA_HIP(hipMemcpyAsync(out, dout.p, (size_t)batch * sizeof(sa_spec_metrics), hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    return SA_OK;
+}
+
+}  // extern "C"

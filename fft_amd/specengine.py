@@ -195,3 +195,181 @@ def synth_analyze(params, vpp=None, n_base=2048, upsample=8, window="gaussian", 
                                             float(win_param), flags, _lib.ptr(mag), _lib.ptr(pb), _lib.ptr(pm),
                                             _lib.ptr(y)))
     return (mag, pb, pm, y) if return_signal else (mag, pb, pm)
+
+
+# ---- derived metrics: the numbers come from the device, the strings are the reference's ----
+def format_freq(f):
+    """SignalGeneratorApp._format_freq (main.py:1747-1755)."""
+    if f < 1e3:
+        return f"{f:.1f} Hz"
+    elif f < 1e6:
+        return f"{f / 1e3:.2f} kHz"
+    elif f < 1e9:
+        return f"{f / 1e6:.2f} MHz"
+    return f"{f / 1e9:.2f} GHz"
+
+
+def time_stats(y):
+    """Device reductions over one frame or a batch of frames (sa_time_stats_f64): returns the ctypes
+    struct (1-D input) or an array of structs ([batch, n] input).  Fields: include/specengine.h."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    if y.ndim not in (1, 2) or y.shape[-1] < 1:
+        raise ValueError("y must be a non-empty frame or a [batch, n] array")
+    batch = 1 if y.ndim == 1 else y.shape[0]
+    out = (_lib.TimeStats * max(batch, 1))()
+    _lib.check(_lib.load().sa_time_stats_f64(_lib.ptr(y), batch, y.shape[-1], out))
+    return out[0] if y.ndim == 1 else out
+
+
+def find_peaks(x, height=None, distance=None, height_rel=None):
+    """scipy.signal.find_peaks(x, height=, distance=)[0] on the device (sa_find_peaks_f64), as the reference
+    calls it (main.py:1034, 1639).  `height_rel` takes the threshold as a fraction of max(x)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if x.ndim != 1:
+        raise ValueError("x must be one-dimensional")
+    n = len(x)
+    if n < 3:
+        return np.empty(0, dtype=np.int64)
+    cap = n // 2 + 1
+    idx = np.empty(cap, dtype=np.int32)
+    cnt = np.zeros(1, dtype=np.int32)
+    h = -np.inf if height is None else float(height)
+    _lib.check(_lib.load().sa_find_peaks_f64(_lib.ptr(x), 1, n, h, 0.0 if height_rel is None else float(height_rel),
+                                             1 if distance is None else int(distance), cap, _lib.ptr(idx), _lib.ptr(cnt)))
+    return idx[:int(cnt[0])].astype(np.int64)
+
+
+def _half_from_shifted(Y):
+    """Bins 0..N//2 out of a length-N |Y| in fftshift order (inverse of mirror_half_to_shifted)."""
+    Y = np.asarray(Y, dtype=np.float64)
+    n = len(Y)
+    half = np.empty(n // 2 + 1, dtype=np.float64)
+    k = (n - 1) // 2
+    half[:k + 1] = Y[n // 2:n // 2 + k + 1]
+    if n % 2 == 0 and n >= 2:
+        half[n // 2] = Y[0]
+    return half
+
+
+def spectral_metrics(mag_half, n, freq_step, side_hz=10.0):
+    """sa_spectral_metrics_f64 on one half spectrum (bins 0..n//2 of a length-n frame) or a batch of them."""
+    m = np.ascontiguousarray(mag_half, dtype=np.float64)
+    if m.shape[-1] != n // 2 + 1:
+        raise ValueError("mag_half must have n//2+1 bins")
+    batch = 1 if m.ndim == 1 else m.shape[0]
+    out = (_lib.SpecMetrics * max(batch, 1))()
+    _lib.check(_lib.load().sa_spectral_metrics_f64(_lib.ptr(m), batch, n, float(freq_step), float(side_hz), out))
+    return out[0] if m.ndim == 1 else out
+
+
+def _zero_cross_freq(t, s):
+    """(rate, freq_est) of main.py:1006-1014 from the device's crossing count and first/last crossing:
+    np.mean(np.diff(t[zc])) telescopes to (t[zc[-1]] - t[zc[0]]) / (len(zc) - 1)."""
+    rate = s.zc_count / (t[-1] - t[0]) if len(t) > 1 else 0
+    freq = None
+    if s.zc_count > 1:
+        avg_period = (t[s.zc_last] - t[s.zc_first]) / (s.zc_count - 1) * 2
+        freq = 1 / avg_period if avg_period > 0 else 0
+    return rate, freq
+
+
+def time_analysis(t, y):
+    """SignalGeneratorApp._calculate_time_analysis(t, y) (main.py:989-1024): same labels, same strings."""
+    s = time_stats(np.asarray(y, dtype=np.float64))
+    t = np.asarray(t)
+    vpp = s.max - s.min
+    rms = np.sqrt(s.mean_sq)
+    crest = s.max_abs / rms if rms > 0 else 0
+    rate, freq = _zero_cross_freq(t, s)
+    return [("Tensão Pico a Pico (Vpp):", f"{vpp:.4f} V"), ("Tensão RMS:", f"{rms:.4f} V"),
+            ("Tensão Média (DC):", f"{s.mean:.4f} V"), ("Fator de Crista:", f"{crest:.4f}"),
+            ("Taxa de Cruzamento por Zero:", f"{rate:.2f} Hz"),
+            ("Frequência Estimada:", f"{freq if freq is not None else 0:.2f} Hz")]
+
+
+def freq_analysis(f, Y):
+    """SignalGeneratorApp._calculate_freq_analysis(f, Y) (main.py:1026-1053) on the full shifted arrays:
+    argmax / sum of squares (sa_time_stats_f64 over Y) and find_peaks(height=5 % of max, distance=10) run
+    on the device; the handful of peak heights is combined here."""
+    f = np.asarray(f)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    s = time_stats(Y)
+    i0 = int(s.argmax)
+    fund_freq, fund_amp = f[i0], Y[i0]
+    peaks = find_peaks(Y, height=s.max * 0.05, distance=10)
+    if len(peaks) > 1 and i0 in peaks:
+        hp = peaks[peaks != i0]
+        thd = np.sqrt(np.sum(Y[hp] ** 2) / (fund_amp ** 2)) * 100 if fund_amp > 0 else 0
+    else:
+        thd = 0
+    noise_power = s.mean_sq * len(Y) - fund_amp ** 2
+    snr = 10 * np.log10(fund_amp ** 2 / noise_power) if noise_power > 0 else float("inf")
+    return [("Frequência Fundamental:", f"{format_freq(fund_freq)}"), ("Amplitude Fundamental:", f"{fund_amp:.4f}"),
+            ("THD (Distorção Harmônica):", f"{thd:.2f}%"),
+            ("SNR (Relação Sinal-Ruído):", f"{snr:.2f} dB" if snr != float("inf") else "∞ dB")]
+
+
+def analysis_panels(last_data, waveform, am_on=False, fm_on=False):
+    """SignalGeneratorApp.update_analysis_panels (main.py:1542-1735) without the widgets: returns
+    (time_panel, freq_panel), the strings it sets keyed by the names of its result variables.
+    Time half from sa_time_stats_f64, frequency half from sa_spectral_metrics_f64 over the half spectrum."""
+    y = np.asarray(last_data["y"], dtype=np.float64)
+    t, f, Y = np.asarray(last_data["t"]), np.asarray(last_data["f"]), np.asarray(last_data["Y"], dtype=np.float64)
+    tp, fp = {}, {}
+    s = time_stats(y) if len(y) > 0 else None
+    if s is not None:
+        n = len(y)
+        vpp = s.max - s.min
+        rms = np.sqrt(s.mean_sq)
+        crest = s.max_abs / rms if rms > 0 else 0
+        rate, freq = _zero_cross_freq(t, s)
+        tp["vpp"], tp["rms"], tp["mean"] = f"{vpp:.4f} V", f"{rms:.4f} V", f"{s.mean:.4f} V"
+        tp["crest_factor"] = f"{crest:.4f}"
+        tp["zero_crossing"] = f"{rate:.2f} Hz" if s.zc_count > 0 else "0 Hz"
+        tp["frequency"] = f"{freq:.2f} Hz" if freq is not None else "---"
+        if (waveform.startswith("Quadrada") or waveform.startswith("Pulso")) and vpp > 0:
+            tp["duty_cycle"] = f"{s.above_mid / n * 100:.1f}%"
+        else:
+            tp["duty_cycle"] = "N/A"
+        tp["peak_to_rms"] = f"{crest:.4f}"
+        with np.errstate(all="ignore"):
+            tp["kurtosis"] = f"{np.float64(s.m4) / np.float64(s.m2) ** 2 - 3.0:.4f}" if n > 3 else "---"
+            tp["skewness"] = f"{np.float64(s.m3) / np.float64(s.m2) ** 1.5:.4f}" if n > 2 else "---"
+    n = len(Y)
+    if n > 0:
+        c = n // 2                                           # shifted index of bin 0
+        step = f[c + 1] if n > 1 else 1.0                    # 1 * (1/(n d)): the factor fftfreq multiplies by
+        m = spectral_metrics(_half_from_shifted(Y), n, step, 10.0)
+        if m.fund_bin < 0:
+            raise ValueError("attempt to get argmax of an empty sequence")     # what np.argmax raises at main.py:1627
+        A, f0 = m.fund_amp, f[c + m.fund_bin]
+        fp["fundamental"], fp["fund_amp"] = format_freq(f0), f"{A:.4f}"
+        if m.n_peaks > 0 and A ** 2 > 0:
+            fp["thd"] = f"{np.sqrt(m.harmonic_power / A ** 2) * 100:.2f}%"
+            fp["harmonics"] = f"{m.harmonic_power / A ** 2:.4f}"
+        else:
+            fp["thd"], fp["harmonics"] = "0%", "0"
+        if A > 0:
+            if m.noise_power > 0:
+                fp["snr"] = f"{10 * np.log10(A ** 2 / m.noise_power):.2f} dB"
+                fp["noise_floor"] = f"{np.sqrt(m.noise_power):.4f}"
+            else:
+                fp["snr"], fp["noise_floor"] = "∞ dB", "---"
+        else:
+            fp["snr"], fp["noise_floor"] = "---", "---"
+        if m.n_peaks > 0 and A > 0 and m.max_spur > 0:
+            fp["sfdr"] = f"{20 * np.log10(A / m.max_spur):.2f} dB"
+        else:
+            fp["sfdr"] = "∞ dB"
+        if A > 0 and m.bw_hi_bin >= 0:
+            fp["bandwidth"] = format_freq(f[c + m.bw_hi_bin] - f[c + m.bw_lo_bin])
+        else:
+            fp["bandwidth"] = "---"
+        if am_on:
+            fp["mod_index"] = f"{(s.max - s.min) / (s.max + s.min) * 100:.1f}%" if s.max + s.min != 0 else "---"
+        elif fm_on:
+            fp["mod_index"] = f"{m.sideband_amp / A * 100:.1f}%" if A > 0 else "---"
+        else:
+            fp["mod_index"] = "N/A"
+        fp["peak_freq"] = format_freq(f[c + m.top_peak_bin]) if m.n_peaks > 0 else "---"
+    return tp, fp

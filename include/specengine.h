@@ -198,6 +198,63 @@ int sa_synth_analyze_dev(const sa_gen_params* params_dev, int64_t batch, int32_t
                          int32_t window, double win_param, int32_t flags, float* mag, int32_t* peak_bin,
                          float* peak_mag, float* y_out, void* stream);
 
+/* ---- f2: time-domain statistics per frame --------------------------------------------
+ * The reductions behind _calculate_time_analysis (main.py:989-1024) and the time half of
+ * update_analysis_panels (main.py:1552-1617): Vpp = max-min, RMS = sqrt(mean_sq), DC = mean, crest =
+ * max_abs/RMS, zero-crossing rate = zc_count/(t[-1]-t[0]), frequency estimate from the first/last
+ * crossing (np.mean(np.diff(t[zc])) telescopes), duty = above_mid/n, scipy.stats.skew = m3/m2^1.5 and
+ * kurtosis = m4/m2^2 - 3 (biased central moments).  All accumulation in fp64. */
+typedef struct sa_time_stats {
+    double  min, max, mean, mean_sq, max_abs;
+    double  m2, m3, m4;                 /* mean((y-mean)^k), k = 2, 3, 4                                  */
+    int64_t zc_count;                   /* #{ i : sign(y[i+1]) != sign(y[i]) }  (np.diff(np.sign(y)))     */
+    int64_t zc_first, zc_last;          /* first / last such i, -1 when there is none                    */
+    int64_t above_mid;                  /* #{ y > (max+min)/2 }  (duty cycle, main.py:1592-1594)          */
+    int64_t argmax, argmin;             /* first index of the maximum / minimum (np.argmax / np.argmin)  */
+} sa_time_stats;
+int sa_time_stats_f64(const double* y, int64_t batch, int64_t n, sa_time_stats* out /*[batch]*/);
+int sa_time_stats_f32_dev(const float* y, int64_t batch, int64_t n, int64_t frame_stride, sa_time_stats* out, void* stream);
+int sa_time_stats_f64_dev(const double* y, int64_t batch, int64_t n, int64_t frame_stride, sa_time_stats* out, void* stream);
+
+/* ---- f1: scipy.signal.find_peaks(x, height=, distance=) per row -----------------------------------------
+ * As called at main.py:1034 (height = 0.05 max, distance = 10) and main.py:1639 (height only):
+ * local maxima with scipy's plateau rule (middle sample, edges never peaks), x[peak] >= height, then for
+ * distance > 1 suppression of peaks closer than `distance` to a higher one, highest first (equal heights:
+ * the later peak is kept).  height = height_rel * max(row) when height_rel > 0, else height_abs
+ * (-inf for none).  idx [batch][max_peaks] ascending peak indices, count [batch]; the host variant
+ * fails with SA_EINVAL if a row has more than max_peaks candidates (n/2 always suffices); the device
+ * variant stores -(candidates) in count for such a row.  work: batch*max_peaks bytes of device scratch. */
+int sa_find_peaks_f64(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel,
+                      int32_t distance, int32_t max_peaks, int32_t* idx, int32_t* count);
+int sa_find_peaks_f64_dev(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel,
+                          int32_t distance, int32_t max_peaks, int32_t* idx, int32_t* count, uint8_t* work,
+                          void* stream);
+
+/* ---- f1: derived spectral metrics of a half spectrum (frequency half of update_analysis_panels,
+ *      main.py:1619-1735) ------------------------------------------------------------------------------
+ * mag [batch][n/2+1] = |Y| of length-n frames as the rfft entry points write them.  Positive bins are
+ * 1..K, K = (n-1)/2 (the f > 0 mask of main.py:1622); f_k = k * freq_step with freq_step = 1/(n d), the
+ * value scipy.fft.fftfreq multiplies by, so the masks compare the same doubles as the reference:
+ *   fundamental (:1627)              fund_bin, fund_amp
+ *   harmonic mask (:1634)            bins harm_lo_bin .. K-1  (f > 0.9 f0 and f < f_K)
+ *   peaks >= 0.05 fund_amp (:1639)   n_peaks, harmonic_power = sum amp^2 (THD :1648, level :1652),
+ *                                    max_spur / top_peak_bin (SFDR :1680-1682, peak frequency :1731)
+ *   noise (:1664-1665)               noise_power = sum mag^2 over positive bins outside the mask (SNR :1668)
+ *   -3 dB band (:1691-1696)          bw_lo_bin, bw_hi_bin: first / last positive bin >= fund_amp/sqrt 2
+ *   sidebands (:1717-1718)           sideband_amp = max mag with |f - f0| < side_hz
+ *   total_power                      sum over the two-sided spectrum of |Y|^2 (np.sum(Y**2), main.py:1043)
+ * Bin fields are -1 when undefined (no positive bin, no peak). */
+typedef struct sa_spec_metrics {
+    double  fund_amp, harmonic_power, max_spur, noise_power, total_power, sideband_amp;
+    int32_t fund_bin, harm_lo_bin, n_peaks, top_peak_bin, bw_lo_bin, bw_hi_bin;
+} sa_spec_metrics;
+int sa_spectral_metrics_f64(const double* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
+                            sa_spec_metrics* out /*[batch]*/);
+int sa_spectral_metrics_f32_dev(const float* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
+                                sa_spec_metrics* out, void* stream);
+int sa_spectral_metrics_f64_dev(const double* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
+                                sa_spec_metrics* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

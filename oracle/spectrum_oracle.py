@@ -357,3 +357,208 @@ def synth_upsample_analyze(p, vpp=None, n_base=2048, upsample=8, win="gaussian",
         yu = y
     mag, pb, pm = rfft_mag_peak(yu[None, :], win, win_param)
     return yu, mag[0], int(pb[0]), float(pm[0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# Derived metrics: CPU restatement of main.py:989-1053 and 1542-1735.
+# find_peaks / kurtosis / skew are the reference's own third-party calls (scipy, main.py:12-13).
+# ---------------------------------------------------------------------------------------------------
+def format_freq(f):
+    """main.py:1747-1755."""
+    if f < 1e3:
+        return f"{f:.1f} Hz"
+    elif f < 1e6:
+        return f"{f / 1e3:.2f} kHz"
+    elif f < 1e9:
+        return f"{f / 1e6:.2f} MHz"
+    return f"{f / 1e9:.2f} GHz"
+
+
+def time_stats(y):
+    """The reductions of main.py:994-1007, 1592-1594, 1607, 1614 as raw numbers (layout of sa_time_stats)."""
+    y = np.asarray(y, dtype=np.float64)
+    n = len(y)
+    zc = np.where(np.diff(np.sign(y)))[0]
+    mean = np.mean(y)
+    d = y - mean
+    return {"min": float(np.min(y)), "max": float(np.max(y)), "mean": float(mean), "mean_sq": float(np.mean(y ** 2)),
+            "max_abs": float(np.max(np.abs(y))), "m2": float(np.mean(d ** 2)), "m3": float(np.mean(d ** 3)),
+            "m4": float(np.mean(d ** 4)), "zc_count": int(len(zc)), "zc_first": int(zc[0]) if len(zc) else -1,
+            "zc_last": int(zc[-1]) if len(zc) else -1,
+            "above_mid": int(np.sum(y > (np.max(y) + np.min(y)) / 2)), "argmax": int(np.argmax(y)),
+            "argmin": int(np.argmin(y)), "n": n}
+
+
+def time_analysis(t, y):
+    """main.py:989-1024 `_calculate_time_analysis`: list of (label, formatted value)."""
+    y = np.array(y)
+    vpp = np.max(y) - np.min(y)
+    rms = np.sqrt(np.mean(y ** 2))
+    mean = np.mean(y)
+    crest_factor = np.max(np.abs(y)) / rms if rms > 0 else 0
+    zero_crossings = np.where(np.diff(np.sign(y)))[0]
+    zero_crossing_rate = len(zero_crossings) / (t[-1] - t[0]) if len(t) > 1 else 0
+    if len(zero_crossings) > 1:
+        avg_period = np.mean(np.diff(t[zero_crossings])) * 2
+        freq_est = 1 / avg_period if avg_period > 0 else 0
+    else:
+        freq_est = 0
+    return [("Tensão Pico a Pico (Vpp):", f"{vpp:.4f} V"), ("Tensão RMS:", f"{rms:.4f} V"),
+            ("Tensão Média (DC):", f"{mean:.4f} V"), ("Fator de Crista:", f"{crest_factor:.4f}"),
+            ("Taxa de Cruzamento por Zero:", f"{zero_crossing_rate:.2f} Hz"),
+            ("Frequência Estimada:", f"{freq_est:.2f} Hz")]
+
+
+def find_peaks(x, height=None, distance=None):
+    """scipy.signal.find_peaks as the reference calls it (main.py:1034, 1639)."""
+    from scipy.signal import find_peaks as _fp
+    return _fp(np.asarray(x, dtype=np.float64), height=height, distance=distance)[0]
+
+
+def freq_analysis(f, Y):
+    """main.py:1026-1053 `_calculate_freq_analysis`: list of (label, formatted value)."""
+    fundamental_idx = np.argmax(Y)
+    fundamental_freq = f[fundamental_idx]
+    fundamental_amp = Y[fundamental_idx]
+    peaks = find_peaks(Y, height=np.max(Y) * 0.05, distance=10)
+    if len(peaks) > 1 and fundamental_idx in peaks:
+        harmonic_peaks = np.delete(peaks, np.where(peaks == fundamental_idx))
+        harmonic_power = np.sum(Y[harmonic_peaks] ** 2)
+        thd = np.sqrt(harmonic_power / (fundamental_amp ** 2)) * 100 if fundamental_amp > 0 else 0
+    else:
+        thd = 0
+    signal_power = np.sum(Y ** 2)
+    noise_power = signal_power - (fundamental_amp ** 2)
+    snr = 10 * np.log10(fundamental_amp ** 2 / noise_power) if noise_power > 0 else float("inf")
+    return [("Frequência Fundamental:", f"{format_freq(fundamental_freq)}"),
+            ("Amplitude Fundamental:", f"{fundamental_amp:.4f}"),
+            ("THD (Distorção Harmônica):", f"{thd:.2f}%"),
+            ("SNR (Relação Sinal-Ruído):", f"{snr:.2f} dB" if snr != float("inf") else "∞ dB")]
+
+
+def spectral_metrics(mag_half, n, freq_step, side_hz=10.0):
+    """Raw numbers behind the frequency half of update_analysis_panels (main.py:1619-1735) from the half
+    spectrum (bins 0..n/2); layout of sa_spec_metrics.  f_k = k * freq_step as scipy.fft.fftfreq builds it."""
+    m = np.asarray(mag_half, dtype=np.float64)
+    K = (n - 1) // 2
+    r = {"fund_bin": -1, "harm_lo_bin": -1, "n_peaks": 0, "top_peak_bin": -1, "bw_lo_bin": -1, "bw_hi_bin": -1,
+         "fund_amp": 0.0, "harmonic_power": 0.0, "max_spur": 0.0, "noise_power": 0.0, "sideband_amp": 0.0}
+    tp = m[0] ** 2 + 2 * np.sum(m[1:K + 1] ** 2)
+    if n % 2 == 0 and n >= 2:
+        tp += m[n // 2] ** 2
+    r["total_power"] = float(tp)
+    if K < 1:
+        return r
+    fpos = np.arange(1, K + 1) * freq_step
+    Yp = m[1:K + 1]
+    i0 = int(np.argmax(Yp))
+    A, f0 = Yp[i0], fpos[i0]
+    hm = (fpos > f0 * 0.9) & (fpos < fpos[-1])
+    ha = Yp[hm]
+    pk = find_peaks(ha, height=A * 0.05)
+    lo = int(np.argmax(fpos > f0 * 0.9)) + 1 if hm.any() else K
+    r.update({"fund_bin": i0 + 1, "fund_amp": float(A), "harm_lo_bin": lo, "n_peaks": int(len(pk)),
+              "harmonic_power": float(np.sum(ha[pk] ** 2)), "noise_power": float(np.sum(Yp[~hm] ** 2))})
+    if len(pk):
+        order = pk[np.argsort(ha[pk], kind="stable")[::-1]]
+        r["max_spur"] = float(np.max(ha[pk]))
+        r["top_peak_bin"] = int(order[0]) + lo
+    ab = Yp >= A / np.sqrt(2)
+    if ab.any():
+        w = np.where(ab)[0]
+        r["bw_lo_bin"], r["bw_hi_bin"] = int(w[0]) + 1, int(w[-1]) + 1
+    sb = (fpos > f0 - side_hz) & (fpos < f0 + side_hz)
+    r["sideband_amp"] = float(np.max(Yp[sb])) if sb.any() else -np.finfo(np.float64).max
+    return r
+
+
+def analysis_panels(last_data, waveform, am_on, fm_on):
+    """main.py:1542-1735 `update_analysis_panels`: the strings it pushes into the two panels,
+    returned as (time_panel: dict, freq_panel: dict)."""
+    from scipy.stats import kurtosis, skew
+    y = np.array(last_data["y"])
+    t, f, Y = last_data["t"], last_data["f"], last_data["Y"]
+    tp, fp = {}, {}
+    if len(y) > 0:
+        vpp = np.max(y) - np.min(y)
+        tp["vpp"] = f"{vpp:.4f} V"
+        rms = np.sqrt(np.mean(y ** 2))
+        tp["rms"] = f"{rms:.4f} V"
+        tp["mean"] = f"{np.mean(y):.4f} V"
+        crest = np.max(np.abs(y)) / rms if rms > 0 else 0
+        tp["crest_factor"] = f"{crest:.4f}"
+        zc = np.where(np.diff(np.sign(y)))[0]
+        tp["zero_crossing"] = f"{len(zc) / (t[-1] - t[0]):.2f} Hz" if len(zc) > 0 else "0 Hz"
+        if len(zc) > 1:
+            avg_period = np.mean(np.diff(t[zc])) * 2
+            freq_est = 1 / avg_period if avg_period > 0 else 0
+            tp["frequency"] = f"{freq_est:.2f} Hz"
+        else:
+            tp["frequency"] = "---"
+        if waveform.startswith("Quadrada") or waveform.startswith("Pulso"):
+            if vpp > 0:
+                thr = (np.max(y) + np.min(y)) / 2
+                tp["duty_cycle"] = f"{np.sum(y > thr) / len(y) * 100:.1f}%"
+            else:
+                tp["duty_cycle"] = "N/A"
+        else:
+            tp["duty_cycle"] = "N/A"
+        tp["peak_to_rms"] = f"{crest:.4f}"
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                tp["kurtosis"] = f"{kurtosis(y):.4f}" if len(y) > 3 else "---"
+                tp["skewness"] = f"{skew(y):.4f}" if len(y) > 2 else "---"
+    if len(Y) > 0:
+        pm = f > 0
+        fpos, Yp = f[pm], Y[pm]
+        i0 = np.argmax(Yp)
+        f0, A = fpos[i0], Yp[i0]
+        fp["fundamental"] = format_freq(f0)
+        fp["fund_amp"] = f"{A:.4f}"
+        hm = (fpos > f0 * 0.9) & (fpos < fpos[-1])
+        hf, ha = fpos[hm], Yp[hm]
+        pk = find_peaks(ha, height=A * 0.05)
+        hp = pk[np.argsort(ha[pk])[::-1]]
+        if len(hp) > 0:
+            hpow, fpow = np.sum(ha[hp] ** 2), A ** 2
+            if fpow > 0:
+                fp["thd"] = f"{np.sqrt(hpow / fpow) * 100:.2f}%"
+                fp["harmonics"] = f"{hpow / fpow:.4f}"
+            else:
+                fp["thd"], fp["harmonics"] = "0%", "0"
+        else:
+            fp["thd"], fp["harmonics"] = "0%", "0"
+        if A > 0:
+            npow = np.sum(Yp[(fpos > 0) & ~hm] ** 2)
+            if npow > 0:
+                fp["snr"] = f"{10 * np.log10(A ** 2 / npow):.2f} dB"
+                fp["noise_floor"] = f"{np.sqrt(npow):.4f}"
+            else:
+                fp["snr"], fp["noise_floor"] = "∞ dB", "---"
+        else:
+            fp["snr"], fp["noise_floor"] = "---", "---"
+        if len(hp) > 0:
+            spur = np.max(ha[hp])
+            fp["sfdr"] = f"{20 * np.log10(A / spur):.2f} dB" if A > 0 and spur > 0 else "∞ dB"
+        else:
+            fp["sfdr"] = "∞ dB"
+        if A > 0:
+            ab = Yp >= A / np.sqrt(2)
+            fp["bandwidth"] = format_freq(fpos[ab][-1] - fpos[ab][0]) if np.any(ab) else "---"
+        else:
+            fp["bandwidth"] = "---"
+        if am_on:
+            a_max, a_min = np.max(y), np.min(y)
+            fp["mod_index"] = f"{(a_max - a_min) / (a_max + a_min) * 100:.1f}%" if a_max + a_min != 0 else "---"
+        elif fm_on:
+            if A > 0:
+                sb = (fpos > f0 - 10) & (fpos < f0 + 10)
+                fp["mod_index"] = f"{np.max(Yp[sb]) / A * 100:.1f}%"
+            else:
+                fp["mod_index"] = "---"
+        else:
+            fp["mod_index"] = "N/A"
+        fp["peak_freq"] = format_freq(hf[hp[0]]) if len(hp) > 0 else "---"
+    return tp, fp
