@@ -212,3 +212,25 @@ def test_metrics_argument_errors():
     idx = np.empty(4, np.int32); cnt = np.empty(1, np.int32)
     assert lib.sa_find_peaks_f64(_lib.ptr(x), 1, 64, -np.inf, 0.0, 1, 4, _lib.ptr(idx), _lib.ptr(cnt)) == _lib.SA_EINVAL
     assert "max_peaks" in _lib.last_error()
+
+
+def test_reference_data_file_and_fnirsi_import(golden_dir):
+    """The one data file the reference ships (dados_sinal.json, N = 2560 = 2^9 * 5 -> Bluestein path) and a
+    FNIRSI dump through import_fnirsi: spectrum to 1e-12, metric strings as the reference prints them."""
+    from fft_amd import formats as F
+    z = np.load(os.path.join(golden_dir, "ref_formats.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "ref_formats.json"), encoding="utf-8"))
+    t, y = z["dados_t"], z["dados_y"]
+    f, Y = S.calculate_fft(t, y)
+    np.testing.assert_array_equal(f, z["dados_f"])
+    assert np.abs(Y - z["dados_Y"]).max() <= 1e-12 * z["dados_Y"].max()
+    m = meta["cases"]["dados"]
+    assert _same_strings([list(x) for x in S.time_analysis(t, y)], m["time_analysis"])
+    assert _same_strings([list(x) for x in S.freq_analysis(f, Y)], m["freq_analysis"])
+    r = F.import_fnirsi(z["f0_file"].tobytes())
+    ld = r["last_data"]
+    assert isinstance(ld["y"], list) and len(ld["y"]) == 1500 and r["voltage_scale"] == meta["cases"]["f0"]["volt_scale"][0]
+    np.testing.assert_array_equal(np.asarray(ld["y"]), z["f0_ch1"])
+    fo, Yo = O.calculate_fft(ld["t"], ld["y"])
+    assert np.abs(ld["Y"] - Yo).max() <= 1e-12 * Yo.max()
+    np.testing.assert_allclose(ld["f"], fo, rtol=1e-15)
