@@ -36,7 +36,8 @@ WAVEFORM_IDS = {name: i for i, name in enumerate(WAVEFORMS)}
 WF_UNKNOWN = 255
 
 
-def validate_inputs(duration, Fc, Fs, Fm, waveform, am_on=False, am_depth=0.5, fm_on=False, fm_dev=50.0):
+def validate_inputs(duration, Fc, Fs, Fm, waveform, am_on=False, am_depth=0.5, fm_on=False, fm_dev=50.0,
+                    late_fork=False):
     """Same checks, same messages, same dict as main.py:492-529 (raises ValueError; the GUI shows it)."""
     p = {"duration": float(duration), "Fc": float(Fc), "Fs": float(Fs), "Fm": float(Fm), "waveform": waveform,
          "am_on": am_on, "am_depth": am_depth, "fm_on": fm_on, "fm_dev": fm_dev}
@@ -52,6 +53,14 @@ def validate_inputs(duration, Fc, Fs, Fm, waveform, am_on=False, am_depth=0.5, f
     max_freq = max(p["Fc"], p["Fm"])
     if max_freq >= p["Fs"] / 2:
         raise ValueError(f"Nyquist violado! Máxima frequência ({max_freq}Hz) deve ser < Fs/2 ({p['Fs'] / 2}Hz).")
+    if late_fork and p["Fc"] > 1e6:
+        # sab10.py:706-724: above 1 MHz keep >= 20 points per cycle and >= 10 cycles (N is not re-evened)
+        if p["Fs"] / p["Fc"] < 20:
+            required_fs = max(p["Fs"], p["Fc"] * 20)
+            if required_fs > p["Fs"]:
+                p["Fs"] = required_fs
+            p["duration"] = max(p["duration"], 10 / p["Fc"])
+            p["N"] = int(p["duration"] * p["Fs"])
     return p
 
 
@@ -106,15 +115,24 @@ def generate(p, vpp=None):
     return t, y
 
 
-def compute(p, vpp=None, window="none", win_param=0.0):
+ANALYSIS_MAX_POINTS = 1000000                                         # sab10.py:43
+
+
+def compute(p, vpp=None, window="none", win_param=0.0, max_points=None):
     """main.py:460-479 -> {'t','y','f','Y'} (all float64 ndarrays of length N, f/Y in fftshift order).
 
     `vpp=None` reproduces the reference's fallback when the Vpp entry does not parse (main.py:467-468).
-    `window` is an extension (the reference applies none); the default keeps parity."""
+    `window` is an extension (the reference applies none); the default keeps parity.
+    `max_points` is the late fork's FFT cap (sab10.py:644-646, ANALYSIS_MAX_POINTS): the spectrum is taken
+    over the first min(N, max_points) samples, so f/Y get that length while t/y keep N."""
     import ctypes as C
-    from .batch import window_id
+    from .batch import fft_mag, window_id
     gp = _gen_params(p, vpp)
     n = gp.N
+    if max_points is not None and n > max_points:
+        t, y = generate(p, vpp)
+        mag, _, _ = fft_mag(y[:max_points], window, win_param)
+        return {"t": t, "y": y, "f": shifted_freq_axis(max_points, p["Fs"]), "Y": mirror_half_to_shifted(mag, max_points)}
     t = np.empty(n, dtype=np.float64)
     y = np.empty(n, dtype=np.float64)
     mag = np.empty(n // 2 + 1, dtype=np.float64)

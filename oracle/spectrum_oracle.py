@@ -23,7 +23,8 @@ TWO_PI = 2 * np.pi
 UNIT_MULTIPLIERS = {"Hz": 1, "kHz": 1e3, "MHz": 1e6, "GHz": 1e9}   # main.py:28
 
 
-def validate_inputs(duration, Fc, Fs, Fm, waveform, am_on=False, am_depth=0.5, fm_on=False, fm_dev=50.0):
+def validate_inputs(duration, Fc, Fs, Fm, waveform, am_on=False, am_depth=0.5, fm_on=False, fm_dev=50.0,
+                    late_fork=False):
     """main.py:492-522. Raises ValueError with the reference's messages."""
     p = {"duration": float(duration), "Fc": float(Fc), "Fs": float(Fs), "Fm": float(Fm),
          "waveform": waveform, "am_on": am_on, "am_depth": am_depth, "fm_on": fm_on, "fm_dev": fm_dev}
@@ -40,6 +41,14 @@ def validate_inputs(duration, Fc, Fs, Fm, waveform, am_on=False, am_depth=0.5, f
     if max_freq >= p["Fs"] / 2:
         raise ValueError(
             f"Nyquist violado! Máxima frequência ({max_freq}Hz) deve ser < Fs/2 ({p['Fs'] / 2}Hz).")
+    if late_fork and p["Fc"] > 1e6:
+        # sab10.py:706-724: above 1 MHz keep >= 20 points per cycle and >= 10 cycles (N is not re-evened)
+        if p["Fs"] / p["Fc"] < 20:
+            required_fs = max(p["Fs"], p["Fc"] * 20)
+            if required_fs > p["Fs"]:
+                p["Fs"] = required_fs
+            p["duration"] = max(p["duration"], 10 / p["Fc"])
+            p["N"] = int(p["duration"] * p["Fs"])
     return p
 
 
@@ -189,16 +198,18 @@ def calculate_fft(t, y):
     return f, np.abs(Y)
 
 
-def compute(p, vpp=None):
-    """main.py:460-479 -> the `last_data` dict."""
+def compute(p, vpp=None, max_points=None):
+    """main.py:460-479 -> the `last_data` dict.  max_points: the late fork's FFT length cap
+    (sab10.py:43, 644-646: fft(y, n=min(N, ANALYSIS_MAX_POINTS)) — f/Y then have that length, t/y keep N)."""
     t = np.arange(p["N"]) / p["Fs"]
     y = generate_waveform(p, t)
     if vpp is not None:
         y = y * (vpp / 2)
     if not p["waveform"].startswith("Onda AM") and not p["waveform"].startswith("Onda FM"):
         y = apply_modulation(p, y, t)
-    Y = sfft.fftshift(sfft.fft(y))
-    f = sfft.fftshift(sfft.fftfreq(p["N"], 1 / p["Fs"]))
+    n_fft = p["N"] if max_points is None else min(p["N"], max_points)
+    Y = sfft.fftshift(sfft.fft(y, n=n_fft))
+    f = sfft.fftshift(sfft.fftfreq(n_fft, 1 / p["Fs"]))
     return {"t": t, "y": y, "f": f, "Y": np.abs(Y)}
 
 

@@ -110,3 +110,17 @@ def test_export_contract():
     rows = list(zip(*d.values()))
     assert len(rows) == 2000 and len(rows[0]) == 4
     json.dumps({k: v.tolist() for k, v in d.items()})
+
+
+def test_compute_with_late_fork_fft_cap():
+    """sab10.py:644-646: fft(y, n=min(N, cap)) — spectrum over the first `cap` samples, t/y keep N."""
+    from oracle import spectrum_oracle as O
+    p = S.validate_inputs(0.1, 1000.0, 20000.0, 100.0, "Onda AM")
+    out = S.compute(p, 2.0, max_points=1500)
+    ref = O.compute(p, 2.0, max_points=1500)
+    assert len(out["t"]) == len(out["y"]) == 2000 and len(out["f"]) == len(out["Y"]) == 1500
+    np.testing.assert_array_equal(out["f"], ref["f"])
+    assert np.abs(out["y"] - ref["y"]).max() <= 1e-12
+    assert np.abs(out["Y"] - ref["Y"]).max() <= 1e-12 * ref["Y"].max()
+    full = S.compute(p, 2.0, max_points=S.ANALYSIS_MAX_POINTS)          # cap above N: the plain path
+    assert len(full["Y"]) == 2000

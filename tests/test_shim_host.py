@@ -61,3 +61,30 @@ def test_waveform_table_covers_every_reference_branch(golden_dir):
     names = {c["p"]["waveform"] for c in meta["cases"]}
     assert len(S.WAVEFORMS) == 33
     assert names - {"nome desconhecido"} <= set(S.WAVEFORMS) - {"Ruído Branco"} | {"Ruído Branco"}
+
+
+def test_late_fork_input_conditioning(golden_dir):
+    """validate_inputs(late_fork=True) == sab10.py:666-741 on the cases captured from the reference
+    (tests/golden/ref_latefork.json): high-Fc Fs/duration auto-adjust, same error texts."""
+    import json
+    import os
+    from fft_amd import specengine as S
+    from oracle import spectrum_oracle as O
+    j = json.load(open(os.path.join(golden_dir, "ref_latefork.json"), encoding="utf-8"))
+    assert j["meta"]["ANALYSIS_MAX_POINTS"] == S.ANALYSIS_MAX_POINTS
+    adjusted = 0
+    for c in j["cases"]:
+        i = c["in"]
+        args = (float(i["duration"]), float(i["Fc"]) * S.UNIT_MULTIPLIERS[i["units_fc"]],
+                float(i["Fs"]) * S.UNIT_MULTIPLIERS[i["units_fs"]], float(i["Fm"]) * S.UNIT_MULTIPLIERS[i["units_fm"]], "Seno")
+        for mod in (S, O):
+            if c["p"] is None:
+                with pytest.raises(ValueError) as e:
+                    mod.validate_inputs(*args, late_fork=True)
+                assert str(e.value) == c["error"]
+            else:
+                p = mod.validate_inputs(*args, late_fork=True)
+                assert p == c["p"], (i, p, c["p"])
+        if c["p"] is not None and c["p"]["Fs"] != args[2]:
+            adjusted += 1
+    assert adjusted >= 3
