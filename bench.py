@@ -79,16 +79,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # Rehearsal aid for a one-GPU box (not used by the driver): SA_BENCH_SHARE_GPU=1 puts every rank on device 0
+    # and swaps RCCL (which refuses two ranks on one device) for gloo; the timed region is unchanged.
+    share = os.environ.get("SA_BENCH_SHARE_GPU") == "1"
+    dev = 0 if share else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     from fft_amd import _lib
     lib = _lib.load()
-    _lib.check(lib.sa_init(local_rank))
+    _lib.check(lib.sa_init(dev))
 
     n = N_POINTS
     batch = 1 << args.log2_batch
@@ -120,7 +125,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
