@@ -190,12 +190,12 @@ int fft_mag_any_dev(const double* dx, int64_t cnt, int64_t n, int window, double
     BluPlan bp{nullptr, nullptr, n};
     if (!pow2) SA_TRY(get_blu_plan(n, st, &bp));
     const int64_t M = pow2 ? n : bp.M;
-    Cd *da = nullptr, *dbuf = nullptr, *dwk = nullptr;
-    SA_HIP(hipMalloc(&da, (size_t)cnt * M * 16));
+    Temp tmp;
+    Cd* da = static_cast<Cd*>(tmp.dev((size_t)cnt * M * 16));
+    Cd* dbuf = static_cast<Cd*>(tmp.dev((size_t)cnt * M * 16));
+    Cd* dwk = M > 4096 ? static_cast<Cd*>(tmp.dev((size_t)cnt * M * 16)) : nullptr;
     int rc = SA_OK;
-    hipError_t e = hipMalloc(&dbuf, (size_t)cnt * M * 16);
-    if (e == hipSuccess && M > 4096) e = hipMalloc(&dwk, (size_t)cnt * M * 16);
-    if (e != hipSuccess) { set_error("fft_mag: hipMalloc failed: %s", hipGetErrorString(e)); rc = SA_ENOMEM; }
+    if (!da || !dbuf || (M > 4096 && !dwk)) rc = SA_ENOMEM;
     const int blocks = num_cus() * 8;
     if (rc == SA_OK) {
         hipLaunchKernelGGL(blu_prep, dim3(blocks), dim3(256), 0, st, dx, dwin, pow2 ? nullptr : bp.chirp, da, n, M, cnt);
@@ -215,10 +215,7 @@ int fft_mag_any_dev(const double* dx, int64_t cnt, int64_t n, int window, double
         if (le == hipSuccess) le = hipStreamSynchronize(st);
         if (le != hipSuccess) { set_error("fft_mag kernels failed: %s", hipGetErrorString(le)); rc = SA_EHIP; }
     }
-    hipFree(da);
-    if (dbuf) hipFree(dbuf);
-    if (dwk) hipFree(dwk);
-    return rc;
+    return rc;            // (the stream was synchronised above, so tmp's blocks are idle)
 }
 
 }  // namespace sa
@@ -241,29 +238,30 @@ extern "C" int sa_fft_mag_f64(const double* x, int64_t batch, int64_t n, int32_t
     int64_t chunk = (int64_t)(1ull << 28) / (Mest * 16);        // <= 256 MiB per work buffer
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
-    double *dx = nullptr, *dmag = nullptr, *dpm = nullptr;
-    int32_t* dpb = nullptr;
+    // device block [x | mag | peak_mag | peak_bin] with a pinned mirror: one H2D and one D2H per chunk
+    const bool wm = (flags & SA_F_WRITE_MAG) != 0;
+    const size_t ox = 0, om = ox + (size_t)chunk * n * 8, opm = om + (wm ? (size_t)chunk * nb * 8 : 0);
+    const size_t opb = opm + (size_t)chunk * 8, total = opb + (((size_t)chunk * 4 + 7) & ~(size_t)7);
+    Temp tmp;
+    char* d = static_cast<char*>(tmp.dev(total));
+    char* h = static_cast<char*>(tmp.pinned(total));
+    if (!d || !h) return SA_ENOMEM;
     int rc = SA_OK;
-    hipError_t e = hipMalloc(&dx, (size_t)chunk * n * 8);
-    if (e == hipSuccess && (flags & SA_F_WRITE_MAG)) e = hipMalloc(&dmag, (size_t)chunk * nb * 8);
-    if (e == hipSuccess) e = hipMalloc(&dpm, (size_t)chunk * 8);
-    if (e == hipSuccess) e = hipMalloc(&dpb, (size_t)chunk * 4);
-    if (e != hipSuccess) { set_error("sa_fft_mag_f64: hipMalloc failed: %s", hipGetErrorString(e)); rc = SA_ENOMEM; }
     for (int64_t b0 = 0; rc == SA_OK && b0 < batch; b0 += chunk) {
         const int64_t cnt = batch - b0 < chunk ? batch - b0 : chunk;
-        e = hipMemcpyAsync(dx, x + b0 * n, (size_t)cnt * n * 8, hipMemcpyHostToDevice, st);
+        memcpy(h + ox, x + b0 * n, (size_t)cnt * n * 8);
+        hipError_t e = hipMemcpyAsync(d + ox, h + ox, (size_t)cnt * n * 8, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { set_error("H2D failed: %s", hipGetErrorString(e)); rc = SA_EHIP; break; }
-        rc = fft_mag_any_dev(dx, cnt, n, window, win_param, flags, dmag, dpb, dpm, st);
+        rc = fft_mag_any_dev(reinterpret_cast<double*>(d + ox), cnt, n, window, win_param, flags,
+                             wm ? reinterpret_cast<double*>(d + om) : nullptr, reinterpret_cast<int32_t*>(d + opb),
+                             reinterpret_cast<double*>(d + opm), st);
         if (rc != SA_OK) break;
-        if (flags & SA_F_WRITE_MAG) e = hipMemcpyAsync(mag + b0 * nb, dmag, (size_t)cnt * nb * 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(peak_bin + b0, dpb, (size_t)cnt * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(peak_mag + b0, dpm, (size_t)cnt * 8, hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(h + om, d + om, total - om, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { set_error("D2H failed: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+        if (e != hipSuccess) { set_error("D2H failed: %s", hipGetErrorString(e)); rc = SA_EHIP; break; }
+        if (wm) memcpy(mag + b0 * nb, h + om, (size_t)cnt * nb * 8);
+        memcpy(peak_mag + b0, h + opm, (size_t)cnt * 8);
+        memcpy(peak_bin + b0, h + opb, (size_t)cnt * 4);
     }
-    if (dx) hipFree(dx);
-    if (dmag) hipFree(dmag);
-    if (dpm) hipFree(dpm);
-    if (dpb) hipFree(dpb);
     return rc;
 }

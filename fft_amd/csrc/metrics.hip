@@ -13,6 +13,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <vector>
 
@@ -388,16 +389,6 @@ static int find_peaks_dev(const double* x, int64_t batch, int64_t n, double heig
     return SA_OK;
 }
 
-// RAII device scratch for the host-pointer entry points
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) {
-        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { p = nullptr; set_error("hipMalloc of %zu bytes failed", bytes); return SA_ENOMEM; }
-        return SA_OK;
-    }
-};
-
 }  // namespace sa
 
 extern "C" {
@@ -417,13 +408,17 @@ int sa_time_stats_f64(const double* y, int64_t batch, int64_t n, sa_time_stats* 
     if (batch == 0) return SA_OK;
     if (!y || !out) { set_error("time_stats: NULL buffer"); return SA_EINVAL; }
     hipStream_t st = thread_stream();
-    DevBuf dy, dout;
-    SA_TRY(dy.alloc((size_t)batch * n * 8));
-    SA_TRY(dout.alloc((size_t)batch * sizeof(sa_time_stats)));
-    SA_HIP(hipMemcpyAsync(dy.p, y, (size_t)batch * n * 8, hipMemcpyHostToDevice, st));
-    SA_TRY(time_stats_dev<double>(static_cast<const double*>(dy.p), batch, n, n, static_cast<sa_time_stats*>(dout.p), st));
-    SA_HIP(hipMemcpyAsync(out, dout.p, (size_t)batch * sizeof(sa_time_stats), hipMemcpyDeviceToHost, st));
+    const size_t xb = (size_t)batch * n * 8, ob = (size_t)batch * sizeof(sa_time_stats);
+    Temp tmp;
+    char* d = static_cast<char*>(tmp.dev(xb + ob));
+    char* h = static_cast<char*>(tmp.pinned(xb + ob));
+    if (!d || !h) return SA_ENOMEM;
+    memcpy(h, y, xb);
+    SA_HIP(hipMemcpyAsync(d, h, xb, hipMemcpyHostToDevice, st));
+    SA_TRY(time_stats_dev<double>(reinterpret_cast<const double*>(d), batch, n, n, reinterpret_cast<sa_time_stats*>(d + xb), st));
+    SA_HIP(hipMemcpyAsync(h + xb, d + xb, ob, hipMemcpyDeviceToHost, st));
     SA_HIP(hipStreamSynchronize(st));
+    memcpy(out, h + xb, ob);
     return SA_OK;
 }
 
@@ -444,17 +439,20 @@ int sa_find_peaks_f64(const double* x, int64_t batch, int64_t n, double height_a
     if (batch == 0) return SA_OK;
     if (!x || !idx || !count) { set_error("find_peaks: NULL buffer"); return SA_EINVAL; }
     hipStream_t st = thread_stream();
-    DevBuf dx, di, dc, ds;
-    SA_TRY(dx.alloc((size_t)batch * n * 8));
-    SA_TRY(di.alloc((size_t)batch * max_peaks * 4));
-    SA_TRY(dc.alloc((size_t)batch * 4));
-    SA_TRY(ds.alloc((size_t)batch * max_peaks));
-    SA_HIP(hipMemcpyAsync(dx.p, x, (size_t)batch * n * 8, hipMemcpyHostToDevice, st));
-    SA_TRY(find_peaks_dev(static_cast<const double*>(dx.p), batch, n, height_abs, height_rel, distance, max_peaks,
-                          static_cast<int32_t*>(di.p), static_cast<int32_t*>(dc.p), static_cast<uint8_t*>(ds.p), st));
-    SA_HIP(hipMemcpyAsync(idx, di.p, (size_t)batch * max_peaks * 4, hipMemcpyDeviceToHost, st));
-    SA_HIP(hipMemcpyAsync(count, dc.p, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
+    const size_t xb = (size_t)batch * n * 8, ib = (size_t)batch * max_peaks * 4, cb = ((size_t)batch * 4 + 7) & ~(size_t)7;
+    Temp tmp;
+    char* d = static_cast<char*>(tmp.dev(xb + ib + cb + (size_t)batch * max_peaks));
+    char* h = static_cast<char*>(tmp.pinned(xb + ib + cb));
+    if (!d || !h) return SA_ENOMEM;
+    memcpy(h, x, xb);
+    SA_HIP(hipMemcpyAsync(d, h, xb, hipMemcpyHostToDevice, st));
+    SA_TRY(find_peaks_dev(reinterpret_cast<const double*>(d), batch, n, height_abs, height_rel, distance, max_peaks,
+                          reinterpret_cast<int32_t*>(d + xb), reinterpret_cast<int32_t*>(d + xb + ib),
+                          reinterpret_cast<uint8_t*>(d + xb + ib + cb), st));
+    SA_HIP(hipMemcpyAsync(h + xb, d + xb, ib + cb, hipMemcpyDeviceToHost, st));
     SA_HIP(hipStreamSynchronize(st));
+    memcpy(idx, h + xb, ib);
+    memcpy(count, h + xb + ib, (size_t)batch * 4);
     for (int64_t b = 0; b < batch; ++b)
         if (count[b] < 0) {
             set_error("find_peaks: row %lld has %d peaks, max_peaks=%d is too small", (long long)b, -count[b], max_peaks);
@@ -481,14 +479,18 @@ int sa_spectral_metrics_f64(const double* mag, int64_t batch, int64_t n, double 
     if (!mag || !out) { set_error("spectral_metrics: NULL buffer"); return SA_EINVAL; }
     hipStream_t st = thread_stream();
     const size_t nb = (size_t)(n / 2 + 1);
-    DevBuf dm, dout;
-    SA_TRY(dm.alloc((size_t)batch * nb * 8));
-    SA_TRY(dout.alloc((size_t)batch * sizeof(sa_spec_metrics)));
-    SA_HIP(hipMemcpyAsync(dm.p, mag, (size_t)batch * nb * 8, hipMemcpyHostToDevice, st));
-    SA_TRY(spectral_metrics_dev<double>(static_cast<const double*>(dm.p), batch, n, freq_step, side_hz,
-                                        static_cast<sa_spec_metrics*>(dout.p), st));
-    SA_HIP(hipMemcpyAsync(out, dout.p, (size_t)batch * sizeof(sa_spec_metrics), hipMemcpyDeviceToHost, st));
+    const size_t xb = (size_t)batch * nb * 8, ob = (size_t)batch * sizeof(sa_spec_metrics);
+    Temp tmp;
+    char* d = static_cast<char*>(tmp.dev(xb + ob));
+    char* h = static_cast<char*>(tmp.pinned(xb + ob));
+    if (!d || !h) return SA_ENOMEM;
+    memcpy(h, mag, xb);
+    SA_HIP(hipMemcpyAsync(d, h, xb, hipMemcpyHostToDevice, st));
+    SA_TRY(spectral_metrics_dev<double>(reinterpret_cast<const double*>(d), batch, n, freq_step, side_hz,
+                                        reinterpret_cast<sa_spec_metrics*>(d + xb), st));
+    SA_HIP(hipMemcpyAsync(h + xb, d + xb, ob, hipMemcpyDeviceToHost, st));
     SA_HIP(hipStreamSynchronize(st));
+    memcpy(out, h + xb, ob);
     return SA_OK;
 }
 

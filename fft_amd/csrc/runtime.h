@@ -55,4 +55,24 @@ const void* get_cached_table(const std::string& key, size_t bytes, void (*fill)(
 
 void free_all_plans();
 
+// Per-call temporary device / pinned-host memory for the host-pointer entry points.  Requests are served by
+// bump allocation from a block cached per host thread (so the GUI's frame-at-a-time calls pay no hipMalloc /
+// hipFree and stage through pinned memory); a request that does not fit falls back to hipMalloc for this call and
+// the cached block grows (up to TEMP_CACHE_MAX) when the outermost Temp of the call ends.  Temps nest (stack
+// discipline).  Every user synchronises its stream before its Temp goes out of scope.
+constexpr size_t TEMP_CACHE_MAX = (size_t)256 << 20;
+class Temp {
+ public:
+    Temp();
+    ~Temp();
+    void* dev(size_t bytes);       // 256-byte aligned; nullptr (+ error message) when out of memory
+    void* pinned(size_t bytes);
+    Temp(const Temp&) = delete;
+    Temp& operator=(const Temp&) = delete;
+ private:
+    size_t dmark_, hmark_;
+    std::vector<void*> dextra_, hextra_;
+};
+void free_thread_caches();         // sa_shutdown: releases the cached blocks of every thread
+
 }  // namespace sa

@@ -71,6 +71,102 @@ hipStream_t thread_stream() {
     return st;
 }
 
+// ---- per-thread temporary memory (class Temp) ---------------------------------------------------------
+struct ThreadCache {
+    int device = -1;
+    char* d = nullptr; size_t dcap = 0, doff = 0, dwant = 0;
+    char* h = nullptr; size_t hcap = 0, hoff = 0, hwant = 0;
+    int depth = 0;
+};
+static std::mutex g_cache_mu;
+static std::vector<ThreadCache*> g_caches;           // every thread's cache, for sa_shutdown
+struct ThreadCacheHolder {
+    ThreadCache* c;
+    ThreadCacheHolder() : c(new ThreadCache) { std::lock_guard<std::mutex> l(g_cache_mu); g_caches.push_back(c); }
+    // not freed at thread exit: the HIP runtime may already be gone; sa_shutdown releases the blocks
+};
+static thread_local ThreadCacheHolder t_cache;
+static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void release_blocks(ThreadCache* c) {
+    if (c->d) (void)hipFree(c->d);
+    if (c->h) (void)hipHostFree(c->h);
+    c->d = c->h = nullptr;
+    c->dcap = c->hcap = c->doff = c->hoff = 0;
+}
+
+Temp::Temp() {
+    ThreadCache* c = t_cache.c;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (c->depth == 0 && c->device != dev) {           // the thread moved to another device: start over there
+        release_blocks(c);
+        c->device = dev;
+    }
+    ++c->depth;
+    dmark_ = c->doff;
+    hmark_ = c->hoff;
+}
+
+Temp::~Temp() {
+    ThreadCache* c = t_cache.c;
+    for (void* p : dextra_) (void)hipFree(p);
+    for (void* p : hextra_) (void)hipHostFree(p);
+    c->doff = dmark_;
+    c->hoff = hmark_;
+    if (--c->depth == 0) {                             // outermost: grow the cached blocks to what this call wanted
+        if (c->dwant > c->dcap && c->dwant <= TEMP_CACHE_MAX) {
+            if (c->d) (void)hipFree(c->d);
+            c->dcap = 0; c->d = nullptr;
+            size_t cap = 1 << 20;
+            while (cap < c->dwant) cap <<= 1;
+            if (hipMalloc(reinterpret_cast<void**>(&c->d), cap) == hipSuccess) c->dcap = cap; else c->d = nullptr;
+        }
+        if (c->hwant > c->hcap && c->hwant <= TEMP_CACHE_MAX) {
+            if (c->h) (void)hipHostFree(c->h);
+            c->hcap = 0; c->h = nullptr;
+            size_t cap = 1 << 20;
+            while (cap < c->hwant) cap <<= 1;
+            if (hipHostMalloc(reinterpret_cast<void**>(&c->h), cap, hipHostMallocDefault) == hipSuccess) c->hcap = cap; else c->h = nullptr;
+        }
+        c->dwant = c->hwant = 0;
+    }
+}
+
+// doff / hoff are VIRTUAL bump offsets (they advance even when a request is served by the hipMalloc fallback),
+// so their high-water mark is the block size that would have served the whole call.
+void* Temp::dev(size_t bytes) {
+    ThreadCache* c = t_cache.c;
+    bytes = round_up(bytes ? bytes : 1, 256);
+    const size_t at = c->doff;
+    c->doff += bytes;
+    if (c->doff > c->dwant) c->dwant = c->doff;
+    if (at + bytes <= c->dcap) return c->d + at;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { set_error("hipMalloc of %zu bytes failed", bytes); return nullptr; }
+    dextra_.push_back(p);
+    return p;
+}
+
+void* Temp::pinned(size_t bytes) {
+    ThreadCache* c = t_cache.c;
+    bytes = round_up(bytes ? bytes : 1, 256);
+    const size_t at = c->hoff;
+    c->hoff += bytes;
+    if (c->hoff > c->hwant) c->hwant = c->hoff;
+    if (at + bytes <= c->hcap) return c->h + at;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc of %zu bytes failed", bytes); return nullptr; }
+    hextra_.push_back(p);
+    return p;
+}
+
+void free_thread_caches() {
+    std::lock_guard<std::mutex> l(g_cache_mu);
+    for (ThreadCache* c : g_caches)
+        if (c->depth == 0) release_blocks(c);
+}
+
 // ---- host table builders ------------------------------------------------------------------------
 // np.hanning / np.hamming / np.blackman (numpy/lib/_function_base_impl.py) and
 // scipy.signal.windows.gaussian(M, std, sym=True): all symmetric, n in [0, N-1], denominator N-1.
@@ -249,6 +345,7 @@ int sa_init(int device) {
 
 void sa_shutdown(void) {
     hipDeviceSynchronize();
+    sa::free_thread_caches();
     sa::free_all_plans();
 }
 

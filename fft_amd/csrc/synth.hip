@@ -11,6 +11,8 @@
 // White noise uses a counter-based Philox stream: statistical parity only (the reference draws from
 // numpy's unseeded global RNG, main.py:553).
 #include "synth_gen.h"
+#include <string.h>
+
 #include "runtime.h"
 
 namespace sa {
@@ -113,31 +115,29 @@ int sa_compute_f64(const sa_gen_params* p, int32_t window, double win_param, int
     flags |= SA_F_WRITE_MAG;
     hipStream_t st = thread_stream();
     const int64_t n = p->N, nb = n / 2 + 1;
-    double *dy = nullptr, *dt = nullptr, *dmag = nullptr, *dpm = nullptr;
-    int32_t* dpb = nullptr;
-    hipError_t e = hipMalloc(&dy, (size_t)n * 8);
-    if (e == hipSuccess && t_out) e = hipMalloc(&dt, (size_t)n * 8);
-    if (e == hipSuccess) e = hipMalloc(&dmag, (size_t)nb * 8);
-    if (e == hipSuccess) e = hipMalloc(&dpm, 8);
-    if (e == hipSuccess) e = hipMalloc(&dpb, 4);
-    int rc = SA_OK;
-    if (e != hipSuccess) { set_error("sa_compute_f64: hipMalloc failed: %s", hipGetErrorString(e)); rc = SA_ENOMEM; }
-    if (rc == SA_OK) rc = synth_dev(*p, dy, dt, st);
-    if (rc == SA_OK) rc = fft_mag_any_dev(dy, 1, n, window, win_param, flags, dmag, dpb, dpm, st);
+    // one device block [y | t | mag | peak_mag | peak_bin] and one pinned mirror: a single D2H per call
+    const size_t oy = 0, ot = oy + (size_t)n * 8, om = ot + (t_out ? (size_t)n * 8 : 0), opm = om + (size_t)nb * 8, opb = opm + 8;
+    const size_t total = opb + 8;
+    Temp tmp;
+    char* d = static_cast<char*>(tmp.dev(total));
+    char* h = static_cast<char*>(tmp.pinned(total));
+    if (!d || !h) return SA_ENOMEM;
+    double* dy = reinterpret_cast<double*>(d + oy);
+    double* dt = t_out ? reinterpret_cast<double*>(d + ot) : nullptr;
+    int rc = synth_dev(*p, dy, dt, st);
+    if (rc == SA_OK)
+        rc = fft_mag_any_dev(dy, 1, n, window, win_param, flags, reinterpret_cast<double*>(d + om),
+                             reinterpret_cast<int32_t*>(d + opb), reinterpret_cast<double*>(d + opm), st);
     if (rc == SA_OK) {
-        e = hipMemcpyAsync(y_out, dy, (size_t)n * 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && t_out) e = hipMemcpyAsync(t_out, dt, (size_t)n * 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(mag, dmag, (size_t)nb * 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(peak_bin, dpb, 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(peak_mag, dpm, 8, hipMemcpyDeviceToHost, st);
+        hipError_t e = hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { set_error("sa_compute_f64: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+        if (e != hipSuccess) { set_error("sa_compute_f64: %s", hipGetErrorString(e)); return SA_EHIP; }
+        memcpy(y_out, h + oy, (size_t)n * 8);
+        if (t_out) memcpy(t_out, h + ot, (size_t)n * 8);
+        memcpy(mag, h + om, (size_t)nb * 8);
+        memcpy(peak_mag, h + opm, 8);
+        memcpy(peak_bin, h + opb, 4);
     }
-    if (dy) hipFree(dy);
-    if (dt) hipFree(dt);
-    if (dmag) hipFree(dmag);
-    if (dpm) hipFree(dpm);
-    if (dpb) hipFree(dpb);
     return rc;
 }
 
