@@ -40,18 +40,30 @@ struct StftArgs {
     float* peak_mag;        // [2][nframes]
 };
 
+// frames per workgroup: small transforms share a workgroup of >= 256 threads
+template <int LR, int PP> constexpr int stft_fpw() {
+    constexpr int tpf = FftPlan<LR, PP>::TPF;
+    return tpf >= 256 ? 1 : 256 / tpf;
+}
+
 template <int LR, int PP>
-__global__ void __launch_bounds__((FftPlan<LR, PP>::TPF))
+__global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * stft_fpw<LR, PP>()), 4)   // >= 4 waves per SIMD: two 512-thread workgroups per CU
 stft_stereo_kernel(StftArgs a) {
     using PL = FftPlan<LR, PP>;
     constexpr int N = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
+    constexpr int FPW = stft_fpw<LR, PP>();
     constexpr int S = LdsPadShift<float>::value;
+    constexpr int LDSF = lds_fft_elems<float, LR>();
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float2* buf = reinterpret_cast<float2*>(smem_raw);
-    constexpr int NW = (TPF + 63) / 64;
-    float* red_m = reinterpret_cast<float*>(buf + lds_fft_elems<float, LR>());
+    float2* smem = reinterpret_cast<float2*>(smem_raw);
+    constexpr int NW = (TPF * FPW + 63) / 64;
+    float* red_m = reinterpret_cast<float*>(smem + FPW * LDSF);
     int* red_k = reinterpret_cast<int*>(red_m + 2 * NW);
-    const int tl = threadIdx.x;
+    // index inside the frame's thread group / frame slot inside the workgroup (slot 0 is a compile-time
+    // constant for one frame per workgroup, so the frame index stays uniform and lives in SGPRs)
+    const int tl = FPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % TPF;
+    const int g = FPW == 1 ? 0 : (int)threadIdx.x / TPF;
+    float2* buf = smem + g * LDSF;
     const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
     const bool wdb = a.flags & SA_F_DB;
     const bool excl = a.flags & SA_F_EXCLUDE_DC_NYQ;
@@ -74,19 +86,33 @@ stft_stereo_kernel(StftArgs a) {
     tw.load(a.twR, tl);
     const uint32_t* pcm = reinterpret_cast<const uint32_t*>(a.pcm);   // one (L,R) pair per dword
     uint32_t raw[P];
-    // Frame loads / spectrum stores go through buffer descriptors built from scalars: one 32-bit lane
-    // offset per access family plus scalar offsets, range-checked by the hardware.
-    auto load_frame = [&](int64_t f, int lane4) {
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(pcm + f * a.hop), 0, N * 4, 0x00020000);
+    // Frame loads / spectrum stores go through buffer descriptors: one 32-bit lane offset per access family plus
+    // scalar offsets, range-checked by the hardware.  With one frame per workgroup the frame base is uniform and
+    // lives in the descriptor; with several, the descriptor spans the record and the frame offset is per lane.
+    const int64_t last = a.nframes - 1;
+    auto load_frame = [&](int64_t f, int lane) {
+        if constexpr (FPW == 1) {
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(pcm + f * a.hop), 0, N * 4, 0x00020000);
 #pragma unroll
-        for (int u = 0; u < P / R0; ++u)
+            for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1)
-                raw[u * R0 + n1] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, (n1 * (N / R0) + TPF * u) * 4, 0);
+                for (int n1 = 0; n1 < R0; ++n1)
+                    raw[u * R0 + n1] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, (n1 * (N / R0) + TPF * u) * 4, 0);
+        } else {
+            const uint32_t* src = pcm + f * a.hop + lane;
+#pragma unroll
+            for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+                for (int n1 = 0; n1 < R0; ++n1) raw[u * R0 + n1] = src[n1 * (N / R0) + TPF * u];
+        }
     };
-    if ((int64_t)blockIdx.x < a.nframes) load_frame(blockIdx.x, tl * 4);
-    for (int64_t f = blockIdx.x; f < a.nframes; f += gridDim.x) {
+    // frames past the end repeat the last frame (every thread reaches the barriers); their stores are dropped
+    const int64_t first = (int64_t)blockIdx.x * FPW;
+    if (first < a.nframes) load_frame(first + g <= last ? first + g : last, tl);
+    for (int64_t base = first; base < a.nframes; base += (int64_t)gridDim.x * FPW) {
+        const bool valid = base + g <= last;
+        const int64_t f = valid ? base + g : last;
         int tq = tl;                             // opaque per frame: nothing below is hoisted out of the loop
         asm volatile("" : "+v"(tq));
         tq &= TPF - 1;
@@ -94,7 +120,10 @@ stft_stereo_kernel(StftArgs a) {
 #pragma unroll
         for (int i = 0; i < P; ++i)
             v[i] = mk<float>((float)(int16_t)(raw[i] & 0xFFFF) * w[i], (float)(int16_t)(raw[i] >> 16) * w[i]);
-        load_frame(f + gridDim.x < a.nframes ? f + gridDim.x : f, tq * 4);   // last round re-reads (L2-hot), unused
+        {
+            const int64_t nb_ = base + (int64_t)gridDim.x * FPW + g;            // next round's frame (clamped, L2-hot, unused at the end)
+            load_frame(nb_ <= last ? nb_ : last, tq);
+        }
         lds_fft_tw<float, LR, PP>(v, buf, tl, tw);
         // ---- split channels, magnitudes, peaks ------------------------------------------------------
         // pair q < N/2 ... thread 0 adds bin N/2 (rows are NB floats; stores past a row are dropped by
@@ -103,18 +132,25 @@ stft_stereo_kernel(StftArgs a) {
         tq &= TPF - 1;
         float bl = -1.f, br = -1.f;
         int kl = 0x7fffffff, kr = 0x7fffffff;
+        const bool st_ok = wmag && valid;
+        float* rowl = a.mag + f * NB;
+        float* rowr = a.mag + (a.nframes + f) * NB;
         const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
-            wmag ? a.mag + f * NB : nullptr, 0, wmag ? NB * 4 : 0, 0x00020000);
+            FPW == 1 && st_ok ? rowl : nullptr, 0, FPW == 1 && st_ok ? NB * 4 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-            wmag ? a.mag + (a.nframes + f) * NB : nullptr, 0, wmag ? NB * 4 : 0, 0x00020000);
+            FPW == 1 && st_ok ? rowr : nullptr, 0, FPW == 1 && st_ok ? NB * 4 : 0, 0x00020000);
         auto emit = [&](int q, int voff, int soff, float2 zq, float2 zm) {
             const float2 L = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
             const float2 Rr = mk<float>(0.5f * (zq.y + zm.y), 0.5f * (zm.x - zq.x));
             const float mL = sqrtf(L.x * L.x + L.y * L.y), mR = sqrtf(Rr.x * Rr.x + Rr.y * Rr.y);
             const float oL = wdb ? 20.0f * log10f(fmaxf(mL, SA_DB_FLOOR_F32)) : mL;
             const float oR = wdb ? 20.0f * log10f(fmaxf(mR, SA_DB_FLOOR_F32)) : mR;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oL), rl, voff, soff, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oR), rr, voff, soff, 0);
+            if constexpr (FPW == 1) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oL), rl, voff, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oR), rr, voff, soff, 0);
+            } else {
+                if (st_ok) { rowl[q] = oL; rowr[q] = oR; }
+            }
             if (!(excl && (q == 0 || q == N / 2))) {
                 if (mL > bl) { bl = mL; kl = q; }   // q ascending per thread: first max kept with '>'
                 if (mR > br) { br = mR; kr = q; }
@@ -138,18 +174,19 @@ stft_stereo_kernel(StftArgs a) {
             if (orr > br || (orr == br && okr < kr)) { br = orr; kr = okr; }
         }
         if constexpr (TPF > 64) {
+            constexpr int WPF = TPF / 64;           // waves per frame
             const int wave = threadIdx.x >> 6;
             if ((threadIdx.x & 63) == 0) { red_m[2 * wave] = bl; red_m[2 * wave + 1] = br; red_k[2 * wave] = kl; red_k[2 * wave + 1] = kr; }
             __syncthreads();
             if (tl == 0)
-                for (int w = 1; w < NW; ++w) {
+                for (int w = g * WPF + 1; w < (g + 1) * WPF; ++w) {
                     const float ol = red_m[2 * w], orr = red_m[2 * w + 1];
                     const int okl = red_k[2 * w], okr = red_k[2 * w + 1];
                     if (ol > bl || (ol == bl && okl < kl)) { bl = ol; kl = okl; }
                     if (orr > br || (orr == br && okr < kr)) { br = orr; kr = okr; }
                 }
         }
-        if (tl == 0) {
+        if (tl == 0 && valid) {
             a.peak_bin[f] = kl; a.peak_mag[f] = bl;
             a.peak_bin[a.nframes + f] = kr; a.peak_mag[a.nframes + f] = br;
         }
@@ -181,16 +218,17 @@ static void fill_win32(void* host, void* ctx) {
 
 template <int LR, int PP>
 static int launch_stereo_pp(const StftArgs& a, hipStream_t st) {
-    constexpr int NW = (FftPlan<LR, PP>::TPF + 63) / 64;
-    constexpr int lds = lds_fft_elems<float, LR>() * 8 + NW * 16 + 16;
+    constexpr int FPW = stft_fpw<LR, PP>();
+    constexpr int NW = (FftPlan<LR, PP>::TPF * FPW + 63) / 64;
+    constexpr int lds = FPW * lds_fft_elems<float, LR>() * 8 + NW * 16 + 16;
     auto kern = stft_stereo_kernel<LR, PP>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    const int64_t cap = (int64_t)num_cus() * 8;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.nframes < cap ? a.nframes : cap)), dim3(FftPlan<LR, PP>::TPF), lds, st, a);
+    const int64_t cap = (int64_t)num_cus() * 8, need = (a.nframes + FPW - 1) / FPW;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(need < cap ? need : cap)), dim3(FftPlan<LR, PP>::TPF * FPW), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
