@@ -61,33 +61,58 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
     Cd* buf = smem + col * LDSF;
     const int64_t groups_per_a = a.S / B;
     const int64_t ngroups = a.batch * a.A * groups_per_a;
-    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const int64_t sg = g % groups_per_a;
-        const int64_t ab = g / groups_per_a;            // = batch * A + a
-        const int64_t s = sg * B + col;
-        const int64_t base = (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + s;
-        Cd v[P];
+    // v holds the group being transformed; once the transform's last LDS write is done v is dead, so the NEXT
+    // group's loads are issued into it before the twiddle/store epilogue and fly during it (no extra registers).
+    Cd v[P];
+    auto load_group = [&](int64_t g) {
+        const int64_t sg = g % groups_per_a, ab = g / groups_per_a;
+        const int64_t base = (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + sg * B + col;
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) {
-                Cd z = a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S];
-                if (a.conj_in) z.y = -z.y;
-                v[u * R0 + n1] = z;
-            }
-        lds_fft<double, LR, C2C_PP>(v, buf, tl, a.twR);
-        // twiddle w_{R S}^{s k} and store, B contiguous columns per k
-        constexpr int NT = TPF * B;
+            for (int n1 = 0; n1 < R0; ++n1) v[u * R0 + n1] = a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S];
+    };
+    if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x);
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int64_t sg = g % groups_per_a;
+        const int64_t ab = g / groups_per_a;            // = batch * A + a
+        if (a.conj_in) {
 #pragma unroll
-        for (int u = 0; u < (R * B) / NT; ++u) {
-            const int idx = threadIdx.x + NT * u;
-            const int c = idx % B, k = idx / B;
-            Cd z = smem[c * LDSF + lds_pad<S>(k)];
-            const int64_t sc = sg * B + c;
-            const int64_t j = sc * k;                    // < R * S
-            const Cd w = cmul(a.thi[j >> a.h], a.tlo[j & ((1 << a.h) - 1)]);
-            z = cmul(z, w);
-            a.out[(ab / a.A) * a.n + (ab % a.A) * (R * a.S) + (int64_t)k * a.S + sc] = z;
+            for (int i = 0; i < P; ++i) v[i].y = -v[i].y;
+        }
+        lds_fft<double, LR, C2C_PP, false>(v, buf, tl, a.twR);
+        // twiddle w^{s k} (w = w_{RS}) and store, B contiguous columns per k.  A thread's outputs are column c
+        // (s = sc), rows k = k0 + TPF u:  w^(sc k) = w^(sc k0) * (w^(sc TPF))^u.  Two table look-ups (requested
+        // before the barrier that publishes the transform) and a product tree of depth <= log2 P replace one
+        // look-up per output (2^30: 33.7 -> 31.0 ms).  Splitting w^(sc k0) further into wave- and column-uniform
+        // factors measured slower (32.6 ms): HBM traffic per pass is already the algorithmic 2 x 17.18 GB.
+        constexpr int NT = TPF * B;
+        constexpr int NU = (R * B) / NT;                 // outputs per thread (= P)
+        const int c = threadIdx.x % B, k0 = threadIdx.x / B;
+        const int64_t sc = sg * B + c;
+        const int64_t hm = ((int64_t)1 << a.h) - 1;
+        auto lookup = [&](int64_t j) { return cmul(a.thi[j >> a.h], a.tlo[j & hm]); };   // j < R * S
+        const Cd w0 = lookup(sc * k0);
+        Cd pw[5];                                        // d^(2^i), d = w^(sc TPF)
+        pw[0] = lookup(sc * TPF);
+        __syncthreads();
+        if (g + gridDim.x < ngroups) load_group(g + gridDim.x);
+#pragma unroll
+        for (int i = 1; (1 << i) < NU; ++i) pw[i] = cmul(pw[i - 1], pw[i - 1]);
+        Cd* outp = a.out + (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + sc;
+        Cd bs[5];                                        // bs[t]: factor of the latest u with ctz(u) == t
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            Cd w;
+            if (u == 0) {
+                w = w0;
+            } else {
+                const int t = __builtin_ctz(u), parent = u & (u - 1);
+                w = cmul(parent == 0 ? w0 : bs[__builtin_ctz(parent)], pw[t]);
+                bs[t] = w;
+            }
+            const int k = k0 + TPF * u;
+            outp[(int64_t)k * a.S] = cmul(smem[c * LDSF + lds_pad<S>(k)], w);
         }
         __syncthreads();
     }
@@ -106,23 +131,27 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_final_pass
     Cd* buf = smem + col * LDSF;
     const int64_t groups_per_t = a.A / B;                // A is a multiple of B (or A == B == 1)
     const int64_t ngroups = a.batch * groups_per_t;
-    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    Cd v[P];                                             // next group's loads fly during the store epilogue (see above)
+    auto load_group = [&](int64_t g) {
         const int64_t b = g / groups_per_t;
-        const int64_t r0 = (g % groups_per_t) * B;      // first natural-order row index "rev"
-        // row handled by this thread's column: rev = k1 + R1 k2  ->  a = k1 R2 + k2
-        const int64_t rev = r0 + col;
+        const int64_t rev = (g % groups_per_t) * B + col;   // natural-order row index: rev = k1 + R1 k2  ->  a = k1 R2 + k2
         const int64_t arow = a.natural ? (rev % a.R1) * a.R2 + rev / a.R1 : rev;
         const Cd* src = a.in + b * a.n + arow * R;
-        Cd v[P];
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) {
-                Cd z = src[n1 * (R / R0) + tl + TPF * u];
-                if (a.conj_in) z.y = -z.y;
-                v[u * R0 + n1] = z;
-            }
+            for (int n1 = 0; n1 < R0; ++n1) v[u * R0 + n1] = src[n1 * (R / R0) + tl + TPF * u];
+    };
+    if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x);
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int64_t b = g / groups_per_t;
+        const int64_t r0 = (g % groups_per_t) * B;      // first natural-order row index of the group
+        if (a.conj_in) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i].y = -v[i].y;
+        }
         lds_fft<double, LR, C2C_PP>(v, buf, tl, a.twR);
+        if (g + gridDim.x < ngroups) load_group(g + gridDim.x);
         constexpr int NT = TPF * B;
 #pragma unroll
         for (int u = 0; u < (R * B) / NT; ++u) {
@@ -156,11 +185,8 @@ template <int LR, int B>
 static int launch_strided(C2cArgs a, hipStream_t st) {
     constexpr int lds = lds_fft_elems<double, LR>() * B * 16;
     auto kern = c2c_strided_pass<LR, B>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t ngroups = a.batch * a.A * (a.S / B);
     const int64_t cap = (int64_t)num_cus() * 16;
     hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR, C2C_PP>::TPF * B), lds, st, a);
@@ -171,11 +197,8 @@ template <int LR, int B>
 static int launch_final(C2cArgs a, hipStream_t st) {
     constexpr int lds = lds_fft_elems<double, LR>() * B * 16;
     auto kern = c2c_final_pass<LR, B>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t ngroups = a.batch * (a.A / B);
     const int64_t cap = (int64_t)num_cus() * 16;
     hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR, C2C_PP>::TPF * B), lds, st, a);

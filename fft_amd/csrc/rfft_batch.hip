@@ -20,11 +20,8 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     constexpr size_t lds = (size_t)FPW * LDS_PER_FRAME * sizeof(cplx<T>) + NWAVES * (sizeof(T) + sizeof(int)) + 16;
     static_assert(lds <= 160 * 1024, "frame does not fit LDS");
     auto kern = rfft_mag_peak_generic<T, LOG2M, P, FPW>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t need = (a.batch + FPW - 1) / FPW;
     const int64_t cap = (int64_t)num_cus() * 8;
     const int grid = (int)(need < cap ? need : cap);
@@ -37,11 +34,8 @@ template <int MODE, int WAVES, bool PF>
 static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st) {
     auto kern = rfft4096_wave_kernel<MODE, WAVES, PF>;
     constexpr int lds = r4k_lds_bytes(WAVES);
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t need = (a.batch + WAVES - 1) / WAVES;
     const int64_t cap = num_cus();                    // persistent: one workgroup per CU
     const int grid = (int)(need < cap ? need : cap);

@@ -15,6 +15,9 @@ void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 int ensure_init();                 // SA_OK or error (message set)
 hipStream_t thread_stream();       // the calling thread's library stream on the current device
 int num_cus();                     // multiprocessor count of the current device
+// Raise a kernel's dynamic-LDS limit on the current device once (the attribute is per device, and a thread may
+// move between devices with sa_set_device); `devs` is the caller's per-kernel bitmask of devices already done.
+int allow_dynamic_lds(const void* kernel, int bytes, uint64_t* devs);
 
 #define SA_HIP(call)                                                                         \
     do {                                                                                     \

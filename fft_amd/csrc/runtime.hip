@@ -71,6 +71,16 @@ hipStream_t thread_stream() {
     return st;
 }
 
+int allow_dynamic_lds(const void* kernel, int bytes, uint64_t* devs) {
+    int dev = 0;
+    SA_HIP(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (*devs & bit) return SA_OK;
+    SA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    *devs |= bit;
+    return SA_OK;
+}
+
 // ---- per-thread temporary memory (class Temp) ---------------------------------------------------------
 struct ThreadCache {
     int device = -1;

@@ -222,11 +222,8 @@ static int launch_stereo_pp(const StftArgs& a, hipStream_t st) {
     constexpr int NW = (FftPlan<LR, PP>::TPF * FPW + 63) / 64;
     constexpr int lds = FPW * lds_fft_elems<float, LR>() * 8 + NW * 16 + 16;
     auto kern = stft_stereo_kernel<LR, PP>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t cap = (int64_t)num_cus() * 8, need = (a.nframes + FPW - 1) / FPW;
     hipLaunchKernelGGL(kern, dim3((unsigned)(need < cap ? need : cap)), dim3(FftPlan<LR, PP>::TPF * FPW), lds, st, a);
     SA_HIP(hipGetLastError());

@@ -237,11 +237,8 @@ static int launch_pipe_pp(const PipeArgs& a, hipStream_t st) {
     constexpr int NW = (FftPlan<LOG2M, PP>::TPF + 63) / 64;
     constexpr int lds = lds_fft_elems<float, LOG2M>() * 8 + (U > 1 ? 2 : 1) * NBASE * 4 + NW * 8 + 16;
     auto kern = synth_pipeline_kernel<LOG2M, U, PP>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t cap = (int64_t)num_cus() * 4;
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(FftPlan<LOG2M, PP>::TPF), lds, st, a);
     SA_HIP(hipGetLastError());
