@@ -1,8 +1,9 @@
 // lds_fft.h — workgroup-cooperative power-of-two complex FFT through LDS (any real type).
 //
-// R = 2^LR points are transformed by TPF = R / P threads holding P points each in registers;
-// radix-8 (then one 4 or 2) decimation-in-frequency passes run in registers with one padded LDS
-// exchange between passes (same scheme as rfft_generic.h).  The result is left in LDS in natural
+// R = 2^LR points are transformed by TPF = R / P threads holding P = 8 or 16 points each in registers;
+// radix-8 / radix-16 (then one smaller) decimation-in-frequency passes run in registers with one padded
+// LDS exchange between passes.  Shared by the generic rfft, STFT, fused-generator and c2c kernels
+// (DESIGN.md §3.2 lists what made it fast).  The result is left in LDS in natural
 // order: buf[lds_pad<S>(k)] = X[k].  Several independent transforms ("columns") can share a
 // workgroup: every thread passes its own column's `buf` and its index `tl` inside the column;
 // the __syncthreads() inside are workgroup-wide, so all threads of the block must call together.

@@ -13,7 +13,6 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     constexpr int M = 1 << LOG2M;
     constexpr int TPF = M / P;
     constexpr int FPW = TPF >= 256 ? 1 : 256 / TPF;
-    constexpr int S = (sizeof(cplx<T>) == 8) ? 5 : 4;
     constexpr int LDS_PER_FRAME = lds_fft_elems<T, LOG2M>();
     constexpr int NTHREADS = TPF * FPW;
     constexpr int NWAVES = (NTHREADS + 63) / 64;

@@ -7,8 +7,8 @@
 // an M-point decimation-in-frequency FFT runs with the data held in registers (P points per
 // thread) and one LDS exchange between radix passes; a Hermitian post-pass turns Z into the
 // n/2+1 real-FFT bins, takes magnitudes, stores them coalesced and reduces the dominant peak.
-// One HBM read of the frame, one HBM write of the spectrum; twiddles / window come from small
-// L2-resident tables (the tuned n=4096 kernel in rfft4096.h keeps them in registers instead).
+// One HBM read of the frame, one HBM write of the spectrum; a thread's twiddles (and, in fp32, its window
+// samples and Hermitian factors) are launch constants held in registers across the frame loop.
 #pragma once
 #include "lds_fft.h"
 
