@@ -92,10 +92,32 @@ class HipEngine:
         return a
 
 
+A2A_MAX_BYTES_PER_PEER = 1 << 30      # keep every per-peer message below 2^31 bytes
+
+
 def _all_to_all(out, inp, group):
+    """out[p] <- rank p's inp[my rank]; out/inp: complex [P][rows][cols] contiguous.
+
+    A per-peer block of 4 GiB (2^28 complex128: a 2^28-point transform on one rank, 2^30 on two) came back
+    untouched from a single all_to_all_single call on this stack (32-bit byte count somewhere below torch), so
+    blocks above A2A_MAX_BYTES_PER_PEER go in row slices; a one-rank group is a plain copy."""
     import torch
     import torch.distributed as dist
-    dist.all_to_all_single(torch.view_as_real(out), torch.view_as_real(inp), group=group)
+    P = dist.get_world_size(group)
+    if P == 1:
+        out.copy_(inp)
+        return
+    per_peer = inp[0].numel() * inp.element_size()
+    if per_peer <= A2A_MAX_BYTES_PER_PEER:
+        dist.all_to_all_single(torch.view_as_real(out), torch.view_as_real(inp), group=group)
+        return
+    rows = inp.shape[1]
+    step = max(1, rows * A2A_MAX_BYTES_PER_PEER // per_peer)
+    for r0 in range(0, rows, step):
+        si = inp[:, r0:r0 + step].contiguous()
+        so = torch.empty_like(si)
+        dist.all_to_all_single(torch.view_as_real(so), torch.view_as_real(si), group=group)
+        out[:, r0:r0 + step].copy_(so)
 
 
 def dist_transpose(a, group=None):

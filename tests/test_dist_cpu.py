@@ -32,5 +32,5 @@ def test_gloo_multiprocess(world):
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
     res = json.loads(line[len("RESULT "):])
-    assert res == {**res, "shard_total_ok": True, "transpose_ok": True, "four_step_ok": True, "gather_ok": True}, res
+    assert res == {**res, "shard_total_ok": True, "transpose_ok": True, "four_step_ok": True, "chunked_a2a_ok": True, "gather_ok": True}, res
     assert res["four_step_err"] < 1e-12
