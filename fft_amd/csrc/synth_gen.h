@@ -28,9 +28,27 @@ __device__ __forceinline__ double sp_sawtooth(double x, double width) {
 __device__ __forceinline__ double sp_square(double x, double duty) {
     return np_mod_2pi(x) < duty * 6.283185307179586 ? 1.0 : -1.0;
 }
+// Trigonometry providers for the generator.  TrigF64 is libm-exact fp64 (the GUI path, 1e-12 parity).
+// TrigF32 serves the fused fp32 pipeline, whose samples are rounded to float anyway: the phase is reduced
+// to a fraction of a turn in fp64 (exact to ~1e-16 |x|), then sinf/cosf of the reduced angle (1 ulp fp32).
+struct TrigF64 {
+    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
+};
+struct TrigF32 {
+    static __device__ __forceinline__ float reduced(double x) {
+        double t = x * 0.15915494309189535;          // turns
+        t -= rint(t);                                // [-0.5, 0.5]
+        return (float)(t * 6.283185307179586);
+    }
+    static __device__ __forceinline__ double sin(double x) { return (double)sinf(reduced(x)); }
+    static __device__ __forceinline__ double cos(double x) { return (double)cosf(reduced(x)); }
+};
+
+template <typename TR = TrigF64>
 __device__ __forceinline__ double np_sinc(double x) {   // sin(pi x)/(pi x), 1 at 0
     const double y = 3.141592653589793 * (x == 0.0 ? 1.0e-20 : x);
-    return sin(y) / y;
+    return TR::sin(y) / y;
 }
 
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -47,6 +65,7 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 }
 
 // One sample of _generate_waveform (main.py:536-615), before the vpp/2 scaling.
+template <typename TR = TrigF64>
 __device__ double gen_sample(const sa_gen_params& p, int64_t n, double tmean) {
     const double pi = 3.141592653589793, two_pi = 6.283185307179586;
     const double t = (double)n / p.Fs;                     // np.arange(N)/Fs  (main.py:460)
@@ -54,8 +73,8 @@ __device__ double gen_sample(const sa_gen_params& p, int64_t n, double tmean) {
     const double Fc = p.Fc, Fm = p.Fm, dur = p.duration;
     const double x = two_pi * Fc * t;                      // ((2*pi)*Fc)*t, numpy's left-to-right order
     switch (p.waveform) {
-        case SA_WF_SENO: return sin(x);
-        case SA_WF_COSSENO: return cos(x);
+        case SA_WF_SENO: return TR::sin(x);
+        case SA_WF_COSSENO: return TR::cos(x);
         case SA_WF_QUADRADA: return sp_square(x, 0.5);
         case SA_WF_TRIANGULAR: return sp_sawtooth(x, 0.5);
         case SA_WF_DENTE_DE_SERRA: return sp_sawtooth(x, 1.0);
@@ -65,48 +84,48 @@ __device__ double gen_sample(const sa_gen_params& p, int64_t n, double tmean) {
             philox4x32((uint32_t)(n >> 1), (uint32_t)((uint64_t)n >> 33), 0x6E6F6973u, 0u, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
             const double u1 = ((double)r[0] + 0.5) / 4294967296.0, u2 = ((double)r[1] + 0.5) / 4294967296.0;
             const double rad = sqrt(-2.0 * log(u1));
-            return 0.5 * rad * ((n & 1) ? sin(two_pi * u2) : cos(two_pi * u2));
+            return 0.5 * rad * ((n & 1) ? TR::sin(two_pi * u2) : TR::cos(two_pi * u2));
         }
-        case SA_WF_EXP_DECAIMENTO: return exp(-t / (dur / 5.0)) * sin(x);
+        case SA_WF_EXP_DECAIMENTO: return exp(-t / (dur / 5.0)) * TR::sin(x);
         case SA_WF_PASSO: { const double tq = (double)(p.N / 4) / p.Fs; return (t - tq) >= 0.0 ? 1.0 : 0.0; }   // heaviside(.,1)
         case SA_WF_RAMPA: return t / tl;
         case SA_WF_PARABOLA: { const double r = t / tl; return r * r; }
         case SA_WF_IMPULSO: return n == p.N / 2 ? 1.0 : 0.0;
         case SA_WF_TANGENTE: { const double v = tan(pi * Fc * t); return fmin(fmax(v, -10.0), 10.0); }
-        case SA_WF_SINC: return np_sinc(2.0 * Fc * t);
-        case SA_WF_GAUSSIANA: { const double d = t - tmean, s = 0.1 * dur; return exp(-(d * d) / (s * s)) * sin(x); }
+        case SA_WF_SINC: return np_sinc<TR>(2.0 * Fc * t);
+        case SA_WF_GAUSSIANA: { const double d = t - tmean, s = 0.1 * dur; return exp(-(d * d) / (s * s)) * TR::sin(x); }
         case SA_WF_CHIRP_LINEAR: {         // scipy chirp 'linear': cos(2 pi (f0 t + 0.5 beta t^2)), f1 = 5 Fc, t1 = t[-1]
             const double beta = (5.0 * Fc - Fc) / tl;
-            return cos(two_pi * (Fc * t + 0.5 * beta * t * t));
+            return TR::cos(two_pi * (Fc * t + 0.5 * beta * t * t));
         }
         case SA_WF_CHIRP_QUADRATICO: {     // 'quadratic', vertex_zero: cos(2 pi (f0 t + beta t^3/3)), f1 = 10 Fc
             const double beta = (10.0 * Fc - Fc) / (tl * tl);
-            return cos(two_pi * (Fc * t + beta * (t * t * t) / 3.0));
+            return TR::cos(two_pi * (Fc * t + beta * (t * t * t) / 3.0));
         }
-        case SA_WF_ONDA_AM: return (1.0 + 0.5 * sin(two_pi * Fm * t)) * sin(x);
-        case SA_WF_ONDA_FM: return sin(x + 5.0 * sin(two_pi * Fm * t));
-        case SA_WF_BATIMENTO: return sin(x) + sin(two_pi * (Fc + Fm) * t);
+        case SA_WF_ONDA_AM: return (1.0 + 0.5 * TR::sin(two_pi * Fm * t)) * TR::sin(x);
+        case SA_WF_ONDA_FM: return TR::sin(x + 5.0 * TR::sin(two_pi * Fm * t));
+        case SA_WF_BATIMENTO: return TR::sin(x) + TR::sin(two_pi * (Fc + Fm) * t);
         case SA_WF_LORENTZIANA: return 1.0 / (1.0 + x * x);
         case SA_WF_HIPERBOLICA: return sinh(x);
         case SA_WF_BESSEL: return j0(x);
-        case SA_WF_SINC_MODULADO: return np_sinc(2.0 * Fc * t) * sin(two_pi * Fm * t);
+        case SA_WF_SINC_MODULADO: return np_sinc<TR>(2.0 * Fc * t) * TR::sin(two_pi * Fm * t);
         case SA_WF_PULSO_GAUSSIANO: {       // scipy gausspulse(t, fc, bw=0.5, bwr=-6): exp(-a t^2) cos(2 pi fc t)
             const double ref = pow(10.0, -6.0 / 20.0);
             const double pb = pi * Fc * 0.5;
             const double a = -(pb * pb) / (4.0 * log(ref));
-            return exp(-a * t * t) * cos(two_pi * Fc * t);
+            return exp(-a * t * t) * TR::cos(two_pi * Fc * t);
         }
         case SA_WF_DENTE_DE_SERRA_MOD: return sp_sawtooth(x, 0.3);
-        case SA_WF_ONDA_AM_DSB: return sin(x) * sin(two_pi * Fm * t);
+        case SA_WF_ONDA_AM_DSB: return TR::sin(x) * TR::sin(two_pi * Fm * t);
         case SA_WF_ONDA_FM_ESTEREO: {
-            const double m = 3.0 * sin(two_pi * Fm * t);
-            return 0.5 * (sin(x + m) + sin(two_pi * (Fc + 1000.0) * t + m));
+            const double m = 3.0 * TR::sin(two_pi * Fm * t);
+            return 0.5 * (TR::sin(x + m) + TR::sin(two_pi * (Fc + 1000.0) * t + m));
         }
-        case SA_WF_QUADRADA_MODULADA: return sp_square(x, 0.5) * (1.0 + 0.5 * sin(two_pi * Fm * t));
-        case SA_WF_TRIANGULAR_MODULADA: return sp_sawtooth(x, 0.5) * (1.0 + 0.3 * sin(two_pi * Fm * t));
-        case SA_WF_PULSO_EXPONENCIAL: return exp(-5.0 * t / dur) * sin(x);
-        case SA_WF_ONDA_COMB: { const double v = sin(x) + 0.7; return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0); }
-        case SA_WF_ONDA_HARMONICA: return sin(x) + 0.5 * sin(two_pi * 2.0 * Fc * t);
+        case SA_WF_QUADRADA_MODULADA: return sp_square(x, 0.5) * (1.0 + 0.5 * TR::sin(two_pi * Fm * t));
+        case SA_WF_TRIANGULAR_MODULADA: return sp_sawtooth(x, 0.5) * (1.0 + 0.3 * TR::sin(two_pi * Fm * t));
+        case SA_WF_PULSO_EXPONENCIAL: return exp(-5.0 * t / dur) * TR::sin(x);
+        case SA_WF_ONDA_COMB: { const double v = TR::sin(x) + 0.7; return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0); }
+        case SA_WF_ONDA_HARMONICA: return TR::sin(x) + 0.5 * TR::sin(two_pi * 2.0 * Fc * t);
         default: return 0.0;                // unknown name -> np.zeros_like(t)  (main.py:614-615)
     }
 }
@@ -117,24 +136,26 @@ __device__ __forceinline__ bool is_premodulated(int wf) {   // names starting "O
 }
 
 // sum_{m=0}^{n} sin(a m)  (closed form of np.cumsum(np.sin(a * arange(N)))[n])
+template <typename TR = TrigF64>
 __device__ __forceinline__ double sin_prefix_sum(double a, int64_t n) {
-    const double sh = sin(0.5 * a);
+    const double sh = TR::sin(0.5 * a);
     if (sh == 0.0) return 0.0;
-    return sin(0.5 * a * (double)n) * sin(0.5 * a * (double)(n + 1)) / sh;
+    return TR::sin(0.5 * a * (double)n) * TR::sin(0.5 * a * (double)(n + 1)) / sh;
 }
 
 // y[n] of main.py:460-472 with the FM integral in closed form.
+template <typename TR = TrigF64>
 __device__ __forceinline__ double modulated_sample(const sa_gen_params& p, int64_t n) {
     const double two_pi = 6.283185307179586;
     const double t = (double)n / p.Fs;
     const bool premod = is_premodulated(p.waveform);
     if (!premod && p.fm_on) {
-        const double acc = sin_prefix_sum(two_pi * p.Fm / p.Fs, n);
-        return sin(two_pi * p.Fc * t + two_pi * p.fm_dev * acc * (1.0 / p.Fs));
+        const double acc = sin_prefix_sum<TR>(two_pi * p.Fm / p.Fs, n);
+        return TR::sin(two_pi * p.Fc * t + two_pi * p.fm_dev * acc * (1.0 / p.Fs));
     }
-    double v = gen_sample(p, n, 0.5 * (double)(p.N - 1) / p.Fs);
+    double v = gen_sample<TR>(p, n, 0.5 * (double)(p.N - 1) / p.Fs);
     if (p.apply_vpp) v = v * p.vpp_half;
-    if (!premod && p.am_on) v = v * (1.0 + p.am_depth * sin(two_pi * p.Fm * t));
+    if (!premod && p.am_on) v = v * (1.0 + p.am_depth * TR::sin(two_pi * p.Fm * t));
     return v;
 }
 

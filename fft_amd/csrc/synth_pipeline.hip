@@ -88,7 +88,7 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
         asm volatile("" : "+v"(tq));
         tq &= TPF - 1;
         // ---- 1. synthesis at the base rate (fp64 phase, fp32 sample) ---------------------------------
-        for (int i = tq; i < NB; i += TPF) yb[i] = (float)modulated_sample(p, i);
+        for (int i = tq; i < NB; i += TPF) yb[i] = (float)modulated_sample<TrigF32>(p, i);
         __syncthreads();
         // ---- 2. knot derivatives (per knot spacing) ---------------------------------------------------
         if constexpr (U > 1) {

@@ -68,7 +68,9 @@ class HipEngine:
         return C.c_void_p(t.data_ptr())
 
     def fft_rows(self, a):
-        """a: complex128 [batch, n] contiguous device tensor; forward FFT of every row, in place."""
+        """a: complex128 [batch, n] contiguous device tensor; forward FFT of every row.  Returns the tensor
+        holding the result: `a` itself for n <= 4096 (in place), otherwise a second buffer (`a` becomes scratch;
+        no copy back)."""
         import torch
         batch, n = a.shape
         stream = self._lib.torch_stream()
@@ -80,9 +82,7 @@ class HipEngine:
         out = torch.empty_like(a) if n > 4096 else a
         self._lib.check(self.lib.sa_fft_c2c_f64_dev(self._ptr(a), self._ptr(out), self._ptr(work) if work is not None else None,
                                                     n, batch, 0, stream))
-        if out is not a:
-            a.copy_(out)
-        return a
+        return out
 
     def twiddle_rows(self, a, row0, n):
         import torch
@@ -148,7 +148,7 @@ def fft_four_step(cols_local, n1, n2, engine, group=None, stats=None):
     assert cols_local.shape == (n1, c) and n1 % P == 0 and n2 % P == 0
     N = n1 * n2
     a = cols_local.t().contiguous()                                  # [c][n1]: local columns as rows
-    engine.fft_rows(a)                                               # (a) FFT over n1 -> k1
+    a = engine.fft_rows(a)                                           # (a) FFT over n1 -> k1
     engine.twiddle_rows(a, r * c, N)                                 # (b) w_N^{n2 k1}
     k1l = n1 // P
     send = a.reshape(c, P, k1l).permute(1, 0, 2).contiguous()        # [P][c][k1l]
@@ -163,8 +163,7 @@ def fft_four_step(cols_local, n1, n2, engine, group=None, stats=None):
         stats["all_to_all_s"] = time.perf_counter() - t0
         stats["bytes_per_peer"] = c * k1l * 16
     b = recv.reshape(P * c, k1l).t().contiguous()                    # [k1l][n2]
-    engine.fft_rows(b)                                               # (d) FFT over n2 -> k2
-    return b
+    return engine.fft_rows(b)                                        # (d) FFT over n2 -> k2
 
 
 def slab_to_columns(slab_local, n1, n2, group=None):
