@@ -64,6 +64,32 @@ __device__ __forceinline__ bool vi_max_first(const ValIdx& a, const ValIdx& b) {
 __device__ __forceinline__ bool vi_min_first(const ValIdx& a, const ValIdx& b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
 __device__ __forceinline__ bool vi_max_last(const ValIdx& a, const ValIdx& b) { return a.v > b.v || (a.v == b.v && a.i > b.i); }
 
+// Group reductions: GT = MT uses the workgroup (LDS + barriers), GT = 64 a single wavefront (shuffles only, no
+// barrier: several frames per workgroup, one per wave — the batch path, where frames are a few thousand samples).
+template <int GT, typename V, typename F>
+__device__ __forceinline__ V group_reduce(V v, F op, V* lds) {
+    if constexpr (GT == 64) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off));
+        return v;
+    } else {
+        return block_reduce(v, op, lds);
+    }
+}
+template <int GT, typename F>
+__device__ __forceinline__ ValIdx group_reduce_vi(ValIdx v, F better, ValIdx* lds) {
+    if constexpr (GT == 64) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const ValIdx o = shfl_xor_vi(v, off);
+            if (better(o, v)) v = o;
+        }
+        return v;
+    } else {
+        return block_reduce_vi(v, better, lds);
+    }
+}
+
 struct SumD { __device__ double operator()(double a, double b) const { return a + b; } };
 struct SumL { __device__ long long operator()(long long a, long long b) const { return a + b; } };
 struct MinL { __device__ long long operator()(long long a, long long b) const { return a < b ? a : b; } };
@@ -71,19 +97,21 @@ struct MaxL { __device__ long long operator()(long long a, long long b) const { 
 struct MaxD { __device__ double operator()(double a, double b) const { return a > b ? a : b; } };
 
 // ---- time-domain statistics ------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int GT>
 __global__ void __launch_bounds__(MT) time_stats_kernel(const T* __restrict__ y, int64_t batch, int64_t n, int64_t stride,
                                                         sa_time_stats* __restrict__ out) {
     __shared__ double ld[MW];
     __shared__ long long ll[MW];
     __shared__ ValIdx lv[MW];
-    for (int64_t f = blockIdx.x; f < batch; f += gridDim.x) {
+    constexpr int GPB = MT / GT;                      // frames (groups) per workgroup
+    const int tid = threadIdx.x % GT;
+    for (int64_t f = (int64_t)blockIdx.x * GPB + threadIdx.x / GT; f < batch; f += (int64_t)gridDim.x * GPB) {
         const T* x = y + f * stride;
         // pass 1: sums, extrema (first index), sign changes  (np.diff(np.sign(y)) != 0 at i, main.py:1006)
         double s1 = 0, s2 = 0, mabs = 0;
         ValIdx mx{-DBL_MAX, 0}, mn{DBL_MAX, 0};
         long long zc = 0, zf = INT64_MAX, zl = -1;
-        for (int64_t i = threadIdx.x; i < n; i += MT) {
+        for (int64_t i = tid; i < n; i += GT) {
             const double v = (double)x[i];
             s1 += v; s2 += v * v;
             mabs = fmax(mabs, fabs(v));
@@ -95,30 +123,30 @@ __global__ void __launch_bounds__(MT) time_stats_kernel(const T* __restrict__ y,
                 if (sv != su) { ++zc; if (i < zf) zf = i; zl = i; }
             }
         }
-        s1 = block_reduce(s1, SumD(), ld);
-        s2 = block_reduce(s2, SumD(), ld);
-        mabs = block_reduce(mabs, MaxD(), ld);
-        mx = block_reduce_vi(mx, vi_max_first, lv);
-        mn = block_reduce_vi(mn, vi_min_first, lv);
-        zc = block_reduce(zc, SumL(), ll);
-        zf = block_reduce(zf, MinL(), ll);
-        zl = block_reduce(zl, MaxL(), ll);
+        s1 = group_reduce<GT>(s1, SumD(), ld);
+        s2 = group_reduce<GT>(s2, SumD(), ld);
+        mabs = group_reduce<GT>(mabs, MaxD(), ld);
+        mx = group_reduce_vi<GT>(mx, vi_max_first, lv);
+        mn = group_reduce_vi<GT>(mn, vi_min_first, lv);
+        zc = group_reduce<GT>(zc, SumL(), ll);
+        zf = group_reduce<GT>(zf, MinL(), ll);
+        zl = group_reduce<GT>(zl, MaxL(), ll);
         const double mean = s1 / (double)n;
         const double mid = (mx.v + mn.v) / 2;           // duty threshold, main.py:1592
         // pass 2: central moments about the mean (scipy.stats moment(), biased) and samples above mid level
         double c2 = 0, c3 = 0, c4 = 0;
         long long above = 0;
-        for (int64_t i = threadIdx.x; i < n; i += MT) {
+        for (int64_t i = tid; i < n; i += GT) {
             const double v = (double)x[i];
             const double d = v - mean, d2 = d * d;
             c2 += d2; c3 += d2 * d; c4 += d2 * d2;
             above += v > mid;
         }
-        c2 = block_reduce(c2, SumD(), ld);
-        c3 = block_reduce(c3, SumD(), ld);
-        c4 = block_reduce(c4, SumD(), ld);
-        above = block_reduce(above, SumL(), ll);
-        if (threadIdx.x == 0) {
+        c2 = group_reduce<GT>(c2, SumD(), ld);
+        c3 = group_reduce<GT>(c3, SumD(), ld);
+        c4 = group_reduce<GT>(c4, SumD(), ld);
+        above = group_reduce<GT>(above, SumL(), ll);
+        if (tid == 0) {
             sa_time_stats r;
             r.min = mn.v; r.max = mx.v; r.mean = mean; r.mean_sq = s2 / (double)n; r.max_abs = mabs;
             r.m2 = c2 / (double)n; r.m3 = c3 / (double)n; r.m4 = c4 / (double)n;
@@ -264,7 +292,7 @@ __global__ void __launch_bounds__(MT) find_peaks_kernel(const T* __restrict__ xa
 // mag row = bins 0 .. n/2 of a length-n frame; positive bins are 1..K, K = (n-1)/2 (the f > 0 mask, :1622;
 // for even n the Nyquist bin sits at -Fs/2 in fftfreq and is not positive).  f_k = k * freq_step, the
 // value scipy.fft.fftfreq produces (k * (1/(n d))), so every frequency comparison below is the reference's.
-template <typename T>
+template <typename T, int GT>
 __global__ void __launch_bounds__(MT) spectral_metrics_kernel(const T* __restrict__ mag_all, int64_t batch, int64_t n,
                                                               int64_t row_stride, double freq_step, double side_hz,
                                                               sa_spec_metrics* __restrict__ out) {
@@ -272,7 +300,9 @@ __global__ void __launch_bounds__(MT) spectral_metrics_kernel(const T* __restric
     __shared__ long long ll[MW];
     __shared__ ValIdx lv[MW];
     const int64_t K = (n - 1) / 2;
-    for (int64_t row = blockIdx.x; row < batch; row += gridDim.x) {
+    constexpr int GPB = MT / GT;
+    const int tid = threadIdx.x % GT;
+    for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / GT; row < batch; row += (int64_t)gridDim.x * GPB) {
         const T* m = mag_all + row * row_stride;
         sa_spec_metrics r;
         r.fund_bin = -1; r.harm_lo_bin = -1; r.n_peaks = 0; r.top_peak_bin = -1; r.bw_lo_bin = -1; r.bw_hi_bin = -1;
@@ -280,13 +310,13 @@ __global__ void __launch_bounds__(MT) spectral_metrics_kernel(const T* __restric
         // two-sided power of the whole spectrum: |Y0|^2 + 2 sum_{1..K} + (even n) |Y_{n/2}|^2   (np.sum(Y**2), :1043)
         double tp = 0;
         ValIdx fx{-DBL_MAX, 0};
-        for (int64_t k = 1 + threadIdx.x; k <= K; k += MT) {
+        for (int64_t k = 1 + tid; k <= K; k += GT) {
             const double v = (double)m[k];
             tp += 2 * v * v;
             if (v > fx.v) { fx.v = v; fx.i = k; }
         }
-        tp = block_reduce(tp, SumD(), ld);
-        fx = block_reduce_vi(fx, vi_max_first, lv);           // np.argmax(Y_positive): first maximum (:1627)
+        tp = group_reduce<GT>(tp, SumD(), ld);
+        fx = group_reduce_vi<GT>(fx, vi_max_first, lv);           // np.argmax(Y_positive): first maximum (:1627)
         if (n >= 1) tp += (double)m[0] * (double)m[0];
         if (n >= 2 && n % 2 == 0) tp += (double)m[n / 2] * (double)m[n / 2];
         r.total_power = tp;
@@ -296,10 +326,12 @@ __global__ void __launch_bounds__(MT) spectral_metrics_kernel(const T* __restric
             r.fund_bin = (int32_t)k0; r.fund_amp = A;
             // harmonic mask (f > 0.9 f0) & (f < f_positive[-1])  (:1634): bins k_lo .. K-1
             const double lim = f0 * 0.9;
-            long long klo = INT64_MAX;
-            for (int64_t k = 1 + threadIdx.x; k <= K; k += MT)
-                if ((double)k * freq_step > lim) { klo = k; break; }     // first k of this thread's stride that passes
-            klo = block_reduce(klo, MinL(), ll);
+            // smallest k with k * freq_step > lim: the predicate is monotone in k, so start next to lim / freq_step
+            // and settle with the reference's own comparison
+            long long klo = (long long)floor(lim / freq_step) - 1;
+            if (klo < 1) klo = 1;
+            while (klo <= K && !((double)klo * freq_step > lim)) ++klo;
+            while (klo > 1 && (double)(klo - 1) * freq_step > lim) --klo;
             if (klo > K) klo = K;                                        // empty mask
             const int64_t khi = K - 1;                                   // last bin inside the mask
             r.harm_lo_bin = (int32_t)klo;
@@ -308,7 +340,7 @@ __global__ void __launch_bounds__(MT) spectral_metrics_kernel(const T* __restric
             double hp = 0;
             long long np_ = 0;
             ValIdx top{-DBL_MAX, -1};
-            for (int64_t i = klo + 1 + threadIdx.x; i < khi; i += MT) {
+            for (int64_t i = klo + 1 + tid; i < khi; i += GT) {
                 int64_t mid;
                 if (local_max_at(m, i, khi, &mid) && (double)m[mid] >= height) {
                     const double v = (double)m[mid];
@@ -316,34 +348,35 @@ __global__ void __launch_bounds__(MT) spectral_metrics_kernel(const T* __restric
                     if (v > top.v || (v == top.v && mid > top.i)) { top.v = v; top.i = mid; }
                 }
             }
-            hp = block_reduce(hp, SumD(), ld);
-            np_ = block_reduce(np_, SumL(), ll);
-            top = block_reduce_vi(top, vi_max_last, lv);
+            hp = group_reduce<GT>(hp, SumD(), ld);
+            np_ = group_reduce<GT>(np_, SumL(), ll);
+            top = group_reduce_vi<GT>(top, vi_max_last, lv);
             r.harmonic_power = hp; r.n_peaks = (int32_t)np_;
             if (np_ > 0) { r.max_spur = top.v; r.top_peak_bin = (int32_t)top.i; }
             // noise: positive bins outside the harmonic mask (:1664-1665), -3 dB band (:1691-1696), sidebands (:1717-1718)
             const double half = A / sqrt(2.0);
             double noise = 0, side = -DBL_MAX;
             long long blo = INT64_MAX, bhi = -1;
-            for (int64_t k = 1 + threadIdx.x; k <= K; k += MT) {
+            for (int64_t k = 1 + tid; k <= K; k += GT) {
                 const double v = (double)m[k], fk = (double)k * freq_step;
                 if (k < klo || k > khi) noise += v * v;
                 if (v >= half) { if (k < blo) blo = k; bhi = k; }
                 if (fk > f0 - side_hz && fk < f0 + side_hz) side = fmax(side, v);
             }
-            noise = block_reduce(noise, SumD(), ld);
-            side = block_reduce(side, MaxD(), ld);
-            blo = block_reduce(blo, MinL(), ll);
-            bhi = block_reduce(bhi, MaxL(), ll);
+            noise = group_reduce<GT>(noise, SumD(), ld);
+            side = group_reduce<GT>(side, MaxD(), ld);
+            blo = group_reduce<GT>(blo, MinL(), ll);
+            bhi = group_reduce<GT>(bhi, MaxL(), ll);
             r.noise_power = noise; r.sideband_amp = side;
             if (bhi >= 0) { r.bw_lo_bin = (int32_t)blo; r.bw_hi_bin = (int32_t)bhi; }
         }
-        if (threadIdx.x == 0) out[row] = r;
-        __syncthreads();
+        if (tid == 0) out[row] = r;
+        if constexpr (GT != 64) __syncthreads();
     }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------
+constexpr int64_t WAVE_ROW_MAX = 16384;      // frames up to this length: one wavefront per frame
 static unsigned grid_for(int64_t batch) {
     const int64_t cap = (int64_t)num_cus() * 8;
     return (unsigned)(batch < cap ? (batch < 1 ? 1 : batch) : cap);
@@ -355,7 +388,10 @@ static int time_stats_dev(const T* y, int64_t batch, int64_t n, int64_t stride, 
     if (batch < 0 || n < 1) { set_error("time_stats: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;
     if (!y || !out) { set_error("time_stats: NULL buffer"); return SA_EINVAL; }
-    hipLaunchKernelGGL(time_stats_kernel<T>, dim3(grid_for(batch)), dim3(MT), 0, st, y, batch, n, stride, out);
+    if (n <= WAVE_ROW_MAX)        // batch path: one wavefront per frame, no barriers
+        hipLaunchKernelGGL((time_stats_kernel<T, 64>), dim3(grid_for((batch + MW - 1) / MW)), dim3(MT), 0, st, y, batch, n, stride, out);
+    else
+        hipLaunchKernelGGL((time_stats_kernel<T, MT>), dim3(grid_for(batch)), dim3(MT), 0, st, y, batch, n, stride, out);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
@@ -367,8 +403,13 @@ static int spectral_metrics_dev(const T* mag, int64_t batch, int64_t n, double f
     if (batch < 0 || n < 1) { set_error("spectral_metrics: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;
     if (!mag || !out) { set_error("spectral_metrics: NULL buffer"); return SA_EINVAL; }
-    hipLaunchKernelGGL(spectral_metrics_kernel<T>, dim3(grid_for(batch)), dim3(MT), 0, st, mag, batch, n, n / 2 + 1, freq_step,
-                       side_hz, out);
+    if (!(freq_step > 0) || !(freq_step < INFINITY)) { set_error("spectral_metrics: freq_step must be a positive finite number"); return SA_EINVAL; }
+    if (n <= WAVE_ROW_MAX)
+        hipLaunchKernelGGL((spectral_metrics_kernel<T, 64>), dim3(grid_for((batch + MW - 1) / MW)), dim3(MT), 0, st, mag, batch, n,
+                           n / 2 + 1, freq_step, side_hz, out);
+    else
+        hipLaunchKernelGGL((spectral_metrics_kernel<T, MT>), dim3(grid_for(batch)), dim3(MT), 0, st, mag, batch, n, n / 2 + 1,
+                           freq_step, side_hz, out);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }

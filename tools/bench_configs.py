@@ -121,6 +121,20 @@ def bench_rfft(n, dtype, log2_total=30):
     return {"config": f"rfft {dtype} n={n}", "batch": batch, "ms": dt * 1e3, "spectra_per_s": batch / dt, "alg_GB_per_s": alg / dt / 1e9}
 
 
+def bench_metrics(log2_batch=20, n=4096):
+    """Derived-metric kernels at C2 size: time statistics over the frames, spectral metrics over the spectra."""
+    batch = 1 << log2_batch
+    x = torch.randn((batch, n), dtype=torch.float32, device="cuda")
+    mag = torch.rand((batch, n // 2 + 1), dtype=torch.float32, device="cuda")
+    ts = torch.empty(batch * C.sizeof(_lib.TimeStats), dtype=torch.uint8, device="cuda")
+    sm = torch.empty(batch * C.sizeof(_lib.SpecMetrics), dtype=torch.uint8, device="cuda")
+    t1 = timeit(lambda: _lib.check(lib.sa_time_stats_f32_dev(P(x), batch, n, n, P(ts), CUR())), 5, 2)
+    t2 = timeit(lambda: _lib.check(lib.sa_spectral_metrics_f32_dev(P(mag), batch, n, 100e3 / n, 10.0, P(sm), CUR())), 5, 2)
+    return {"config": f"metrics at C2 size ({batch} x {n} fp32)", "time_stats_ms": t1 * 1e3,
+            "time_stats_GB_per_s_one_read": batch * n * 4 / t1 / 1e9, "spectral_metrics_ms": t2 * 1e3,
+            "spectral_metrics_GB_per_s_one_read": batch * (n // 2 + 1) * 4 / t2 / 1e9, "ms": t1 * 1e3}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c4", "c5"]
     results = []
@@ -128,6 +142,8 @@ if __name__ == "__main__":
         for dtype in ("f32", "f64"):
             for lg in range(6, 15):
                 results.append(bench_rfft(1 << lg, dtype)); print(json.dumps(results[-1]), flush=True)
+    if "metrics" in which:
+        results.append(bench_metrics()); print(json.dumps(results[-1]), flush=True)
     if "stft" in which:
         for lg in range(8, 14):
             results.append(bench_c3(28, 1 << lg, (1 << lg) // 4)); print(json.dumps(results[-1]), flush=True)
