@@ -375,6 +375,238 @@ __global__ void __launch_bounds__(MT) spectral_metrics_kernel(const T* __restric
     }
 }
 
+// ---- batch variants: one wavefront per frame, 32-bit indices, compares in the input type --------------------
+// Same results as the kernels above (selections are exact in either type: float -> double is monotone; sums are
+// fp64), about a quarter of the instructions: no 64-bit index bookkeeping, no fp64 compares for fp32 input, each
+// sample's sign class computed once and passed to the left neighbour with a lane shuffle.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+// (value, index) argmax over the wave; LAST: among equal values keep the larger index, else the smaller
+template <typename T, bool LAST>
+__device__ __forceinline__ void wave_argmax(T& v, int& i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(i, off);
+        if (ov > v || (ov == v && (LAST ? oi > i : oi < i))) { v = ov; i = oi; }
+    }
+}
+template <typename T> __device__ __forceinline__ int sign_class(T v) { return (v > (T)0) - (v < (T)0); }
+
+template <typename T>
+__global__ void __launch_bounds__(MT) time_stats_wave_kernel(const T* __restrict__ y, int64_t batch, int n, int64_t stride,
+                                                             sa_time_stats* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const T big = sizeof(T) == 4 ? (T)FLT_MAX : (T)DBL_MAX;
+    for (int64_t f = (int64_t)blockIdx.x * MW + (threadIdx.x >> 6); f < batch; f += (int64_t)gridDim.x * MW) {
+        const T* x = y + f * stride;
+        double s1 = 0, s2 = 0;
+        T mx = -big, mn = big, mabs = 0;
+        int imx = 0, imn = 0, zc = 0, zf = INT32_MAX, zl = -1;
+        // UNR sweeps of 64 samples per step: their loads are issued together (one load in flight per wave would
+        // leave the kernel latency bound at ~1 us per 256 bytes)
+        constexpr int UNR = 8;
+        for (int i0 = 0; i0 < n; i0 += 64 * UNR) {
+            T vv[UNR], nx[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                // unconditional loads at clamped indices (no branch around a load); lane 63's right neighbour
+                // lives in the next sweep, the other lanes get theirs by shuffle
+                const int i = i0 + 64 * u + lane;
+                const T a = x[i < n ? i : n - 1];
+                vv[u] = i < n ? a : (T)0;
+                nx[u] = x[i + 1 < n ? i + 1 : n - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = i0 + 64 * u + lane;
+                const bool in = i < n;
+                const T v = vv[u];
+                const double dv = (double)v;
+                s1 += dv;                               // out-of-range lanes add exact zeros
+                s2 = fma(dv, dv, s2);
+                // selects, not branches: the loop body stays one basic block
+                const bool gt = in & (v > mx), lt = in & (v < mn);
+                mx = gt ? v : mx; imx = gt ? i : imx;
+                mn = lt ? v : mn; imn = lt ? i : imn;
+                mabs = fmax(mabs, fabs(v));
+                const int sv = sign_class(v);
+                int su = __shfl_down(sv, 1);            // sign class of sample i + 1
+                su = lane == 63 ? sign_class(nx[u]) : su;
+                const bool cr = (i + 1 < n) & (sv != su);
+                zc += cr;
+                zf = cr & (i < zf) ? i : zf;
+                zl = cr ? i : zl;
+            }
+        }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        {   // max |y|, extrema with first index
+            int dummy = 0;
+            wave_argmax<T, false>(mabs, dummy);
+            wave_argmax<T, false>(mx, imx);
+            T nmn = -mn;
+            wave_argmax<T, false>(nmn, imn);
+            mn = -nmn;
+        }
+        zc = wave_sum(zc); zf = wave_min(zf); zl = wave_max(zl);
+        const double mean = s1 / (double)n;
+        const double mid = ((double)mx + (double)mn) / 2;          // duty threshold, main.py:1592
+        double c2 = 0, c3 = 0, c4 = 0;
+        int above = 0;
+        for (int i0 = 0; i0 < n; i0 += 64 * UNR) {
+            T vv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = i0 + 64 * u + lane;
+                vv[u] = x[i < n ? i : n - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const bool in = i0 + 64 * u + lane < n;
+                const double dv = (double)vv[u];
+                const double d = in ? dv - mean : 0.0, d2 = d * d;
+                c2 += d2; c3 = c3 + d2 * d; c4 = c4 + d2 * d2;
+                above += in & (dv > mid);
+            }
+        }
+        c2 = wave_sum(c2); c3 = wave_sum(c3); c4 = wave_sum(c4); above = wave_sum(above);
+        if (lane == 0) {
+            sa_time_stats r;
+            r.min = (double)mn; r.max = (double)mx; r.mean = mean; r.mean_sq = s2 / (double)n; r.max_abs = (double)mabs;
+            r.m2 = c2 / (double)n; r.m3 = c3 / (double)n; r.m4 = c4 / (double)n;
+            r.zc_count = zc; r.zc_first = zc ? zf : -1; r.zc_last = zl;
+            r.above_mid = above; r.argmax = imx; r.argmin = imn;
+            out[f] = r;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(MT) spectral_metrics_wave_kernel(const T* __restrict__ mag_all, int64_t batch, int n,
+                                                                   int64_t row_stride, double freq_step, double side_hz,
+                                                                   sa_spec_metrics* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int K = (n - 1) / 2;
+    const T big = sizeof(T) == 4 ? (T)FLT_MAX : (T)DBL_MAX;
+    for (int64_t row = (int64_t)blockIdx.x * MW + (threadIdx.x >> 6); row < batch; row += (int64_t)gridDim.x * MW) {
+        const T* m = mag_all + row * row_stride;
+        sa_spec_metrics r;
+        r.fund_bin = -1; r.harm_lo_bin = -1; r.n_peaks = 0; r.top_peak_bin = -1; r.bw_lo_bin = -1; r.bw_hi_bin = -1;
+        r.fund_amp = 0; r.harmonic_power = 0; r.max_spur = 0; r.noise_power = 0; r.total_power = 0; r.sideband_amp = 0;
+        double tp = 0;
+        T fa = -big;
+        int fk = 0;
+        constexpr int UNR = 8;                                  // loads of UNR sweeps in flight together
+        for (int k0 = 1; k0 <= K; k0 += 64 * UNR) {
+            T vv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int k = k0 + 64 * u + lane;
+                vv[u] = m[k <= K ? k : K];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int k = k0 + 64 * u + lane;
+                const bool in = k <= K;
+                const double dv = in ? (double)vv[u] : 0.0;
+                tp = fma(2.0 * dv, dv, tp);
+                const bool g = in & (vv[u] > fa);
+                fa = g ? vv[u] : fa; fk = g ? k : fk;
+            }
+        }
+        tp = wave_sum(tp);
+        wave_argmax<T, false>(fa, fk);                          // np.argmax(Y_positive): first maximum (:1627)
+        tp += (double)m[0] * (double)m[0];
+        if (n >= 2 && n % 2 == 0) tp += (double)m[n / 2] * (double)m[n / 2];
+        r.total_power = tp;
+        if (K >= 1) {
+            const int k0 = fk;
+            const double A = (double)fa, f0 = (double)k0 * freq_step;
+            r.fund_bin = k0; r.fund_amp = A;
+            const double lim = f0 * 0.9;                        // harmonic mask (:1634): bins klo .. K-1
+            int klo = (int)floor(lim / freq_step) - 1;
+            if (klo < 1) klo = 1;
+            while (klo <= K && !((double)klo * freq_step > lim)) ++klo;
+            while (klo > 1 && (double)(klo - 1) * freq_step > lim) --klo;
+            if (klo > K) klo = K;
+            const int khi = K - 1;
+            r.harm_lo_bin = klo;
+            const double height = A * 0.05, half = A / sqrt(2.0);
+            // one sweep over the positive bins: peaks of m[klo..khi] >= 0.05 A (:1639), noise outside the mask
+            // (:1664), -3 dB band (:1691-1696), sidebands (:1717)
+            double hp = 0, noise = 0;
+            int np_ = 0, tk = -1, blo = INT32_MAX, bhi = -1;
+            T tv = -big, side = -big;
+            for (int kk = 1; kk <= K; kk += 64 * UNR) {
+                T vv[UNR], pv_[UNR], nv_[UNR];               // bin k, its left and right neighbours (clamped, unconditional loads)
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int k = kk + 64 * u + lane, kc = k <= K ? k : K;
+                    vv[u] = m[kc];
+                    pv_[u] = m[kc - 1];
+                    nv_[u] = m[kc + 1 <= K ? kc + 1 : K];
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int k = kk + 64 * u + lane;
+                    const bool in = k <= K;
+                    const T v = vv[u];
+                    const double dv = (double)v;
+                    const double sq = dv * dv;
+                    noise += (in & ((k < klo) | (k > khi))) ? sq : 0.0;
+                    const bool hb = in & (dv >= half);
+                    blo = hb & (k < blo) ? k : blo;
+                    bhi = hb ? k : bhi;
+                    const double fq = (double)k * freq_step;
+                    const bool sb = in & (fq > f0 - side_hz) & (fq < f0 + side_hz);
+                    side = sb & (v > side) ? v : side;
+                    if (in & (k > klo) & (k < khi) & (pv_[u] < v)) {   // a rise into k: peak if a strict fall follows the flat top
+                        int j = k + 1;
+                        T nv = nv_[u];
+                        while (j < khi && nv == v) { ++j; nv = m[j]; }
+                        if (nv < v) {
+                            const int mid = (k + (j - 1)) / 2;
+                            const T pv = m[mid];
+                            if ((double)pv >= height) {
+                                hp = fma((double)pv, (double)pv, hp); ++np_;
+                                if (pv > tv || (pv == tv && mid > tk)) { tv = pv; tk = mid; }
+                            }
+                        }
+                    }
+                }
+            }
+            hp = wave_sum(hp); noise = wave_sum(noise); np_ = wave_sum(np_);
+            blo = wave_min(blo); bhi = wave_max(bhi);
+            wave_argmax<T, true>(tv, tk);
+            int dummy = 0;
+            wave_argmax<T, false>(side, dummy);
+            r.harmonic_power = hp; r.n_peaks = np_; r.noise_power = noise;
+            r.sideband_amp = side == -big ? -DBL_MAX : (double)side;
+            if (np_ > 0) { r.max_spur = (double)tv; r.top_peak_bin = tk; }
+            if (bhi >= 0) { r.bw_lo_bin = blo; r.bw_hi_bin = bhi; }
+        }
+        if (lane == 0) out[row] = r;
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------
 constexpr int64_t WAVE_ROW_MAX = 16384;      // frames up to this length: one wavefront per frame
 static unsigned grid_for(int64_t batch) {
@@ -389,7 +621,7 @@ static int time_stats_dev(const T* y, int64_t batch, int64_t n, int64_t stride, 
     if (batch == 0) return SA_OK;
     if (!y || !out) { set_error("time_stats: NULL buffer"); return SA_EINVAL; }
     if (n <= WAVE_ROW_MAX)        // batch path: one wavefront per frame, no barriers
-        hipLaunchKernelGGL((time_stats_kernel<T, 64>), dim3(grid_for((batch + MW - 1) / MW)), dim3(MT), 0, st, y, batch, n, stride, out);
+        hipLaunchKernelGGL(time_stats_wave_kernel<T>, dim3(grid_for((batch + MW - 1) / MW)), dim3(MT), 0, st, y, batch, (int)n, stride, out);
     else
         hipLaunchKernelGGL((time_stats_kernel<T, MT>), dim3(grid_for(batch)), dim3(MT), 0, st, y, batch, n, stride, out);
     SA_HIP(hipGetLastError());
@@ -405,7 +637,7 @@ static int spectral_metrics_dev(const T* mag, int64_t batch, int64_t n, double f
     if (!mag || !out) { set_error("spectral_metrics: NULL buffer"); return SA_EINVAL; }
     if (!(freq_step > 0) || !(freq_step < INFINITY)) { set_error("spectral_metrics: freq_step must be a positive finite number"); return SA_EINVAL; }
     if (n <= WAVE_ROW_MAX)
-        hipLaunchKernelGGL((spectral_metrics_kernel<T, 64>), dim3(grid_for((batch + MW - 1) / MW)), dim3(MT), 0, st, mag, batch, n,
+        hipLaunchKernelGGL(spectral_metrics_wave_kernel<T>, dim3(grid_for((batch + MW - 1) / MW)), dim3(MT), 0, st, mag, batch, (int)n,
                            n / 2 + 1, freq_step, side_hz, out);
     else
         hipLaunchKernelGGL((spectral_metrics_kernel<T, MT>), dim3(grid_for(batch)), dim3(MT), 0, st, mag, batch, n, n / 2 + 1,
