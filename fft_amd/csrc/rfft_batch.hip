@@ -4,6 +4,10 @@
 
 #include "rfft_generic.h"
 #include "rfft4096.h"
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "runtime.h"
 
 namespace sa {
@@ -166,6 +170,9 @@ template int rfft_peak_dev<double>(const double*, int64_t, int32_t, int32_t, dou
 template int rfft_peak_dev<float>(const float*, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);
 
 // Host-pointer variant: stage through device memory in chunks, synchronise before returning.
+// One chunk: upload, kernel, download on the thread's stream.  Several chunks: a 3-deep pipeline — this thread
+// uploads chunk c and launches its kernel while a helper thread downloads chunk c-1 on a second stream (copies
+// to and from pageable memory block their caller, so overlapping the two PCIe directions takes two host threads).
 template <typename T>
 int rfft_peak_host(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
                    T* mag, int32_t* peak_bin, T* peak_mag) {
@@ -176,45 +183,109 @@ int rfft_peak_host(const T* x, int64_t batch, int32_t n, int32_t window, double 
     hipStream_t st = thread_stream();
     const bool wmag = (flags & SA_F_WRITE_MAG) != 0;
     const int64_t nb = n / 2 + 1;
-    // chunk so that the staging buffers stay <= ~1 GiB
-    int64_t chunk = (int64_t)(1ull << 30) / ((int64_t)n * sizeof(T));
+    int64_t chunk = (int64_t)(64ull << 20) / ((int64_t)n * sizeof(T));      // 64 MiB of input per chunk
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
-    T *dx = nullptr, *dmag = nullptr, *dpm = nullptr;
-    int32_t* dpb = nullptr;
-    int rc = SA_OK;
-    auto cleanup = [&]() {
-        if (dx) hipFree(dx);
-        if (dmag) hipFree(dmag);
-        if (dpm) hipFree(dpm);
-        if (dpb) hipFree(dpb);
-    };
-#define SA_HIP_C(call)                                                                        \
-    do {                                                                                      \
-        hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess) {                                                               \
-            set_error("%s failed: %s", #call, hipGetErrorString(e_));                         \
-            cleanup();                                                                        \
-            return (e_ == hipErrorOutOfMemory) ? SA_ENOMEM : SA_EHIP;                         \
-        }                                                                                     \
-    } while (0)
-    SA_HIP_C(hipMalloc(&dx, chunk * n * sizeof(T)));
-    if (wmag) SA_HIP_C(hipMalloc(&dmag, chunk * nb * sizeof(T)));
-    SA_HIP_C(hipMalloc(&dpm, chunk * sizeof(T)));
-    SA_HIP_C(hipMalloc(&dpb, chunk * sizeof(int32_t)));
-    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
-        const int64_t nbt = (batch - b0 < chunk) ? batch - b0 : chunk;
-        SA_HIP_C(hipMemcpyAsync(dx, x + b0 * n, nbt * n * sizeof(T), hipMemcpyHostToDevice, st));
-        rc = rfft_peak_dev<T>(dx, nbt, n, window, win_param, flags, dmag, dpb, dpm, st);
-        if (rc != SA_OK) { cleanup(); return rc; }
-        if (wmag) SA_HIP_C(hipMemcpyAsync(mag + b0 * nb, dmag, nbt * nb * sizeof(T), hipMemcpyDeviceToHost, st));
-        SA_HIP_C(hipMemcpyAsync(peak_bin + b0, dpb, nbt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        SA_HIP_C(hipMemcpyAsync(peak_mag + b0, dpm, nbt * sizeof(T), hipMemcpyDeviceToHost, st));
-        SA_HIP_C(hipStreamSynchronize(st));
+    const int64_t nchunks = (batch + chunk - 1) / chunk;
+    const int NBUF = nchunks > 1 ? 3 : 1;
+    struct Set { T* x; T* mag; T* pm; int32_t* pb; hipEvent_t done; };
+    Set sets[3] = {};
+    Temp tmp;
+    for (int i = 0; i < NBUF; ++i) {
+        sets[i].x = static_cast<T*>(tmp.dev((size_t)chunk * n * sizeof(T)));
+        sets[i].mag = wmag ? static_cast<T*>(tmp.dev((size_t)chunk * nb * sizeof(T))) : nullptr;
+        sets[i].pm = static_cast<T*>(tmp.dev((size_t)chunk * sizeof(T)));
+        sets[i].pb = static_cast<int32_t*>(tmp.dev((size_t)chunk * sizeof(int32_t)));
+        if (!sets[i].x || (wmag && !sets[i].mag) || !sets[i].pm || !sets[i].pb) return SA_ENOMEM;
     }
-#undef SA_HIP_C
-    cleanup();
-    return SA_OK;
+    auto download = [&](const Set& s, int64_t b0, int64_t cnt, hipStream_t q) -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (wmag) e = hipMemcpyAsync(mag + b0 * nb, s.mag, (size_t)cnt * nb * sizeof(T), hipMemcpyDeviceToHost, q);
+        if (e == hipSuccess) e = hipMemcpyAsync(peak_bin + b0, s.pb, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, q);
+        if (e == hipSuccess) e = hipMemcpyAsync(peak_mag + b0, s.pm, (size_t)cnt * sizeof(T), hipMemcpyDeviceToHost, q);
+        if (e == hipSuccess) e = hipStreamSynchronize(q);
+        return e;
+    };
+    if (NBUF == 1) {
+        SA_HIP(hipMemcpyAsync(sets[0].x, x, (size_t)batch * n * sizeof(T), hipMemcpyHostToDevice, st));
+        SA_TRY(rfft_peak_dev<T>(sets[0].x, batch, n, window, win_param, flags, sets[0].mag, sets[0].pb, sets[0].pm, st));
+        SA_HIP(download(sets[0], 0, batch, st));
+        return SA_OK;
+    }
+    // ---- pipelined path ---------------------------------------------------------------------------------------
+    int dev = 0;
+    SA_HIP(hipGetDevice(&dev));
+    hipStream_t st2 = nullptr;
+    SA_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    for (int i = 0; i < NBUF; ++i)
+        if (hipEventCreateWithFlags(&sets[i].done, hipEventDisableTiming) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(sets[j].done);
+            (void)hipStreamDestroy(st2);
+            set_error("hipEventCreate failed");
+            return SA_EHIP;
+        }
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t launched = 0, retired = 0;        // chunks whose kernel is enqueued / whose results are on the host
+    bool stop = false;
+    hipError_t werr = hipSuccess;
+    auto helper_fn = [&]() {
+        if (hipSetDevice(dev) != hipSuccess) { std::lock_guard<std::mutex> l(mu); werr = hipErrorInvalidDevice; stop = true; cv.notify_all(); return; }
+        for (int64_t c = 0; c < nchunks; ++c) {
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return launched > c || stop; });
+                if (launched <= c) return;                 // the producer gave up
+            }
+            const Set& s = sets[c % NBUF];
+            const int64_t b0 = c * chunk, cnt = batch - b0 < chunk ? batch - b0 : chunk;
+            hipError_t e = hipStreamWaitEvent(st2, s.done, 0);
+            if (e == hipSuccess) e = download(s, b0, cnt, st2);
+            std::lock_guard<std::mutex> l(mu);
+            if (e != hipSuccess) { werr = e; stop = true; cv.notify_all(); return; }
+            retired = c + 1;
+            cv.notify_all();
+        }
+    };
+    std::thread helper;
+    try {
+        helper = std::thread(helper_fn);
+    } catch (...) {                                            // no exception may cross the C ABI
+        for (int i = 0; i < NBUF; ++i) (void)hipEventDestroy(sets[i].done);
+        (void)hipStreamDestroy(st2);
+        set_error("could not start the download thread");
+        return SA_EHIP;
+    }
+    int rc = SA_OK;
+    for (int64_t c = 0; c < nchunks && rc == SA_OK; ++c) {
+        {
+            std::unique_lock<std::mutex> l(mu);
+            cv.wait(l, [&] { return retired + NBUF > c || stop; });          // buffer set c % NBUF is free again
+            if (stop) break;
+        }
+        const Set& s = sets[c % NBUF];
+        const int64_t b0 = c * chunk, cnt = batch - b0 < chunk ? batch - b0 : chunk;
+        hipError_t e = hipMemcpyAsync(s.x, x + b0 * n, (size_t)cnt * n * sizeof(T), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); rc = SA_EHIP; break; }
+        rc = rfft_peak_dev<T>(s.x, cnt, n, window, win_param, flags, s.mag, s.pb, s.pm, st);
+        if (rc != SA_OK) break;
+        e = hipEventRecord(s.done, st);
+        if (e != hipSuccess) { set_error("hipEventRecord failed: %s", hipGetErrorString(e)); rc = SA_EHIP; break; }
+        std::lock_guard<std::mutex> l(mu);
+        launched = c + 1;
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> l(mu);
+        if (rc != SA_OK) stop = true;
+        cv.notify_all();
+    }
+    helper.join();
+    (void)hipStreamSynchronize(st);
+    for (int i = 0; i < NBUF; ++i) (void)hipEventDestroy(sets[i].done);
+    (void)hipStreamDestroy(st2);
+    if (rc == SA_OK && werr != hipSuccess) { set_error("D2H copy failed: %s", hipGetErrorString(werr)); rc = SA_EHIP; }
+    return rc;
 }
 
 // ---- synthetic C2 frames: Philox4x32-10 keyed by seed, counter = (frame, sample group) ---------

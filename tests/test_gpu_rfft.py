@@ -144,3 +144,26 @@ def test_large_batch_device_resident_properties():
     np.testing.assert_array_equal(pb, pb2)
     for b in (dx, dm, dpb, dpm):
         b.free()
+
+
+def test_host_path_pipelined_chunks_match_single_chunk():
+    """Host-pointer entry point with more than one 64 MiB chunk (3-deep upload / compute / download pipeline with
+    a helper thread) must return exactly what the single-chunk path returns for the same frames."""
+    import fft_amd
+    rng = np.random.default_rng(77)
+    n, batch = 4096, 3 * 4096 + 17                       # 3 full chunks of 4096 frames + a ragged tail
+    x = rng.standard_normal((batch, n)).astype(np.float32)
+    mag, pb, pm = fft_amd.rfft_peak(x, "hann")
+    for lo in (0, 4096, 8192, 12288):
+        hi = min(lo + 4096, batch)
+        m1, b1, p1 = fft_amd.rfft_peak(x[lo:hi], "hann")  # <= 64 MiB: single chunk
+        np.testing.assert_array_equal(mag[lo:hi], m1)
+        np.testing.assert_array_equal(pb[lo:hi], b1)
+        np.testing.assert_array_equal(pm[lo:hi], p1)
+    _, pb2, pm2 = fft_amd.rfft_peak(x, "hann", write_mag=False)
+    np.testing.assert_array_equal(pb2, pb)
+    x64 = rng.standard_normal((2 * 2048 + 5, n))         # fp64: 2048 frames per chunk
+    m64, b64, _ = fft_amd.rfft_peak(x64, "hamming")
+    m1, b1, _ = fft_amd.rfft_peak(x64[2048:4096], "hamming")
+    np.testing.assert_array_equal(m64[2048:4096], m1)
+    np.testing.assert_array_equal(b64[2048:4096], b1)
