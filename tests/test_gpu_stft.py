@@ -56,3 +56,26 @@ def test_stft_edges():
         fft_amd.stft_pcm16(np.zeros((5000, 2), np.int16), 1000, 250)                # nfft not a power of two
     with pytest.raises(ValueError):
         fft_amd.stft_pcm16(np.zeros((5000, 2), np.float32), 1024, 256)
+
+
+@pytest.mark.parametrize("nfft", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
+def test_stft_stereo_every_size_ragged_frame_count(nfft):
+    """Every stereo kernel instantiation (1 ... 128 frames per workgroup, 8 or 16 points per thread) with a frame
+    count that is not a multiple of the frames-per-workgroup, so the last workgroup carries idle frame slots;
+    also the peak-only, dB and DC/Nyquist-excluded modes against the linear spectrum of the same call."""
+    import fft_amd
+    hop = max(1, nfft // 4)
+    nframes = 131                                            # prime: never a multiple of the slots per workgroup
+    pcm = synth_pcm((nframes - 1) * hop + nfft, 2, nfft + 1)
+    check(pcm, nfft, hop, "hann")
+    mag, pb, pm = fft_amd.stft_pcm16(pcm, nfft, hop, "hann")
+    assert mag.shape == (2, nframes, nfft // 2 + 1)
+    _, pb0, pm0 = fft_amd.stft_pcm16(pcm, nfft, hop, "hann", write_mag=False)
+    np.testing.assert_array_equal(pb0, pb)
+    np.testing.assert_array_equal(pm0, pm)
+    magx, pbx, _ = fft_amd.stft_pcm16(pcm, nfft, hop, "hann", exclude_dc_nyq=True)
+    np.testing.assert_array_equal(magx, mag)
+    np.testing.assert_array_equal(pbx, 1 + np.argmax(mag[..., 1:nfft // 2], axis=-1))
+    db, pbd, _ = fft_amd.stft_pcm16(pcm, nfft, hop, "hann", db=True)
+    np.testing.assert_array_equal(pbd, pb)
+    np.testing.assert_allclose(db, 20 * np.log10(np.maximum(mag, 1e-30)), rtol=0, atol=2e-4)
