@@ -10,6 +10,8 @@
 // One HBM read of the frame, one HBM write of the spectrum; a thread's twiddles (and, in fp32, its window
 // samples and Hermitian factors) are launch constants held in registers across the frame loop.
 #pragma once
+#include <type_traits>
+
 #include "lds_fft.h"
 
 namespace sa {
@@ -126,40 +128,47 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
         const bool wmag = (a.flags & 1) != 0 && a.mag != nullptr && valid;
         const bool wdb = (a.flags & 2) != 0;
         T* mf = a.mag + (valid ? frame : 0) * (int64_t)(M + 1);
+        // The dB conversion is a uniform run-time choice: two instantiations of the epilogue behind one scalar
+        // branch (as a select, every output would pay the logarithm whether it is wanted or not).
+        auto epilogue = [&](auto DBT) {
+            constexpr bool DB = decltype(DBT)::value;
+            auto out = [&](T m) { return DB ? (T)20 * log10(fmax(m, a.db_floor)) : m; };
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int q = tq + TPF * u;
-            const C zq = buf[lds_pad<S>(q)];
-            const C zm = buf[lds_pad<S>((M - q) & (M - 1))];
-            // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
-            const C e = mk<T>((T)0.5 * (zq.x + zm.x), (T)0.5 * (zq.y - zm.y));
-            const C d = mk<T>((T)0.5 * (zq.x - zm.x), (T)0.5 * (zq.y + zm.y));
-            const C wo = cmul(mk<T>(d.y, -d.x), tn[u]);
-            const C xa = cadd(e, wo);            // X[q]
-            const C xb = csub(e, wo);            // conj(X[M-q])
-            const T ma = sqrt(xa.x * xa.x + xa.y * xa.y);
-            const T mb = sqrt(xb.x * xb.x + xb.y * xb.y);
-            const int ka = q, kb = M - q;
-            if (wmag) {
-                mf[ka] = wdb ? (T)20 * log10(fmax(ma, a.db_floor)) : ma;
-                mf[kb] = wdb ? (T)20 * log10(fmax(mb, a.db_floor)) : mb;
+            for (int u = 0; u < NIT; ++u) {
+                const int q = tq + TPF * u;
+                const C zq = buf[lds_pad<S>(q)];
+                const C zm = buf[lds_pad<S>((M - q) & (M - 1))];
+                // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
+                const C e = mk<T>((T)0.5 * (zq.x + zm.x), (T)0.5 * (zq.y - zm.y));
+                const C d = mk<T>((T)0.5 * (zq.x - zm.x), (T)0.5 * (zq.y + zm.y));
+                const C wo = cmul(mk<T>(d.y, -d.x), tn[u]);
+                const C xa = cadd(e, wo);            // X[q]
+                const C xb = csub(e, wo);            // conj(X[M-q])
+                const T ma = sqrt(xa.x * xa.x + xa.y * xa.y);
+                const T mb = sqrt(xb.x * xb.x + xb.y * xb.y);
+                const int ka = q, kb = M - q;
+                if (wmag) { mf[ka] = out(ma); mf[kb] = out(mb); }
+                const bool ga = !(excl && ka == 0) && peak_better(ma, ka, best, best_k);
+                best = ga ? ma : best; best_k = ga ? ka : best_k;
+                const bool gb = !(excl && kb == M) && peak_better(mb, kb, best, best_k);
+                best = gb ? mb : best; best_k = gb ? kb : best_k;
             }
-            if (!(excl && ka == 0) && peak_better(ma, ka, best, best_k)) { best = ma; best_k = ka; }
-            if (!(excl && kb == M) && peak_better(mb, kb, best, best_k)) { best = mb; best_k = kb; }
-        }
-        if (tq == 0) {                           // bin M/2: X = conj(Z[M/2])
-            const C z = buf[lds_pad<S>(M / 2)];
-            const T m = sqrt(z.x * z.x + z.y * z.y);
-            if (wmag) mf[M / 2] = wdb ? (T)20 * log10(fmax(m, a.db_floor)) : m;
-            if (peak_better(m, M / 2, best, best_k)) { best = m; best_k = M / 2; }
-        }
+            if (tq == 0) {                           // bin M/2: X = conj(Z[M/2])
+                const C z = buf[lds_pad<S>(M / 2)];
+                const T m = sqrt(z.x * z.x + z.y * z.y);
+                if (wmag) mf[M / 2] = out(m);
+                if (peak_better(m, M / 2, best, best_k)) { best = m; best_k = M / 2; }
+            }
+        };
+        if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});
         // reduce (best, best_k) over the TPF threads of this frame
         constexpr int WREDUCE = TPF < 64 ? TPF : 64;
 #pragma unroll
         for (int off = WREDUCE / 2; off > 0; off >>= 1) {
             const T om = __shfl_xor(best, off);
             const int ok = __shfl_xor(best_k, off);
-            if (peak_better(om, ok, best, best_k)) { best = om; best_k = ok; }
+            const bool tk = peak_better(om, ok, best, best_k);
+            best = tk ? om : best; best_k = tk ? ok : best_k;
         }
         if constexpr (TPF > 64) {
             const int wave = threadIdx.x >> 6;

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "lds_fft.h"
@@ -139,39 +140,46 @@ stft_stereo_kernel(StftArgs a) {
             FPW == 1 && st_ok ? rowl : nullptr, 0, FPW == 1 && st_ok ? NB * 4 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
             FPW == 1 && st_ok ? rowr : nullptr, 0, FPW == 1 && st_ok ? NB * 4 : 0, 0x00020000);
-        auto emit = [&](int q, int voff, int soff, float2 zq, float2 zm) {
-            const float2 L = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
-            const float2 Rr = mk<float>(0.5f * (zq.y + zm.y), 0.5f * (zm.x - zq.x));
-            const float mL = sqrtf(L.x * L.x + L.y * L.y), mR = sqrtf(Rr.x * Rr.x + Rr.y * Rr.y);
-            const float oL = wdb ? 20.0f * log10f(fmaxf(mL, SA_DB_FLOOR_F32)) : mL;
-            const float oR = wdb ? 20.0f * log10f(fmaxf(mR, SA_DB_FLOOR_F32)) : mR;
-            if constexpr (FPW == 1) {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oL), rl, voff, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oR), rr, voff, soff, 0);
-            } else {
-                if (st_ok) { rowl[q] = oL; rowr[q] = oR; }
+        // The dB conversion is a uniform run-time choice: two instantiations of the epilogue behind one scalar
+        // branch (as a select, every output would pay the logarithm whether it is wanted or not).
+        auto epilogue = [&](auto DBT) {
+            constexpr bool DB = decltype(DBT)::value;
+            auto emit = [&](int q, int voff, int soff, float2 zq, float2 zm) {
+                const float2 L = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
+                const float2 Rr = mk<float>(0.5f * (zq.y + zm.y), 0.5f * (zm.x - zq.x));
+                const float mL = sqrtf(L.x * L.x + L.y * L.y), mR = sqrtf(Rr.x * Rr.x + Rr.y * Rr.y);
+                const float oL = DB ? 20.0f * log10f(fmaxf(mL, SA_DB_FLOOR_F32)) : mL;
+                const float oR = DB ? 20.0f * log10f(fmaxf(mR, SA_DB_FLOOR_F32)) : mR;
+                if constexpr (FPW == 1) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oL), rl, voff, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oR), rr, voff, soff, 0);
+                } else {
+                    if (st_ok) { rowl[q] = oL; rowr[q] = oR; }
+                }
+                const bool ok = !(excl && (q == 0 || q == N / 2));
+                const bool gl = ok & (mL > bl), gr = ok & (mR > br);     // q ascending per thread: first max kept with '>'
+                bl = gl ? mL : bl; kl = gl ? q : kl;
+                br = gr ? mR : br; kr = gr ? q : kr;
+            };
+#pragma unroll
+            for (int u = 0; u < (N / 2) / TPF; ++u) {
+                const int q = tq + TPF * u;
+                emit(q, tq * 4, TPF * u * 4, buf[lds_pad<S>(q)], buf[lds_pad<S>((N - q) & (N - 1))]);
             }
-            if (!(excl && (q == 0 || q == N / 2))) {
-                if (mL > bl) { bl = mL; kl = q; }   // q ascending per thread: first max kept with '>'
-                if (mR > br) { br = mR; kr = q; }
+            if (tq == 0) {
+                const float2 z = buf[lds_pad<S>(N / 2)];
+                emit(N / 2, 0, (N / 2) * 4, z, z);
             }
         };
-#pragma unroll
-        for (int u = 0; u < (N / 2) / TPF; ++u) {
-            const int q = tq + TPF * u;
-            emit(q, tq * 4, TPF * u * 4, buf[lds_pad<S>(q)], buf[lds_pad<S>((N - q) & (N - 1))]);
-        }
-        if (tq == 0) {
-            const float2 z = buf[lds_pad<S>(N / 2)];
-            emit(N / 2, 0, (N / 2) * 4, z, z);
-        }
+        if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});
         constexpr int WRED = TPF < 64 ? TPF : 64;
 #pragma unroll
         for (int off = WRED / 2; off > 0; off >>= 1) {
             const float ol = __shfl_xor(bl, off), orr = __shfl_xor(br, off);
             const int okl = __shfl_xor(kl, off), okr = __shfl_xor(kr, off);
-            if (ol > bl || (ol == bl && okl < kl)) { bl = ol; kl = okl; }
-            if (orr > br || (orr == br && okr < kr)) { br = orr; kr = okr; }
+            const bool tl_ = (ol > bl) | ((ol == bl) & (okl < kl)), tr_ = (orr > br) | ((orr == br) & (okr < kr));
+            bl = tl_ ? ol : bl; kl = tl_ ? okl : kl;
+            br = tr_ ? orr : br; kr = tr_ ? okr : kr;
         }
         if constexpr (TPF > 64) {
             constexpr int WPF = TPF / 64;           // waves per frame

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "lds_fft.h"
@@ -149,32 +150,38 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
         int bk = 0x7fffffff;
         const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
             wmag ? a.mag + f * (M + 1) : nullptr, 0, wmag ? (M + 1) * 4 : 0, 0x00020000);   // zero-length: stores dropped
-        auto consider = [&](float m, int k, int voff, int soff) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wdb ? 20.f * log10f(fmaxf(m, SA_DB_FLOOR_F32)) : m), mrs, voff, soff, 0);
-            if (excl && (k == 0 || k == M)) return;
-            if (m > best || (m == best && k < bk)) { best = m; bk = k; }
-        };
+        // dB is a uniform run-time choice: two instantiations of the epilogue behind one scalar branch
+        auto epilogue = [&](auto DBT) {
+            constexpr bool DB = decltype(DBT)::value;
+            auto consider = [&](float m, int k, int voff, int soff) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(DB ? 20.f * log10f(fmaxf(m, SA_DB_FLOOR_F32)) : m), mrs, voff, soff, 0);
+                const bool g = !(excl && (k == 0 || k == M)) && (m > best || (m == best && k < bk));
+                best = g ? m : best; bk = g ? k : bk;
+            };
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) {                 // pair q < M/2 -> bins q and M - q
-            const int q = tq + TPF * u;
-            const float2 zq = buf[lds_pad<S>(q)], zm = buf[lds_pad<S>((M - q) & (M - 1))];
-            const float2 e = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
-            const float2 d = mk<float>(0.5f * (zq.x - zm.x), 0.5f * (zq.y + zm.y));
-            const float2 wo = cmul(mk<float>(d.y, -d.x), tn[u]);
-            const float2 xa = cadd(e, wo), xb = csub(e, wo);
-            consider(sqrtf(xa.x * xa.x + xa.y * xa.y), q, tq * 4, TPF * u * 4);
-            consider(sqrtf(xb.x * xb.x + xb.y * xb.y), M - q, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
-        }
-        if (tq == 0) {                                  // bin M/2: X = conj(Z[M/2])
-            const float2 z = buf[lds_pad<S>(M / 2)];
-            consider(sqrtf(z.x * z.x + z.y * z.y), M / 2, 0, (M / 2) * 4);
-        }
+            for (int u = 0; u < NIT; ++u) {                 // pair q < M/2 -> bins q and M - q
+                const int q = tq + TPF * u;
+                const float2 zq = buf[lds_pad<S>(q)], zm = buf[lds_pad<S>((M - q) & (M - 1))];
+                const float2 e = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
+                const float2 d = mk<float>(0.5f * (zq.x - zm.x), 0.5f * (zq.y + zm.y));
+                const float2 wo = cmul(mk<float>(d.y, -d.x), tn[u]);
+                const float2 xa = cadd(e, wo), xb = csub(e, wo);
+                consider(sqrtf(xa.x * xa.x + xa.y * xa.y), q, tq * 4, TPF * u * 4);
+                consider(sqrtf(xb.x * xb.x + xb.y * xb.y), M - q, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
+            }
+            if (tq == 0) {                                  // bin M/2: X = conj(Z[M/2])
+                const float2 z = buf[lds_pad<S>(M / 2)];
+                consider(sqrtf(z.x * z.x + z.y * z.y), M / 2, 0, (M / 2) * 4);
+            }
+        };
+        if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});
         constexpr int WRED = TPF < 64 ? TPF : 64;
 #pragma unroll
         for (int off = WRED / 2; off > 0; off >>= 1) {
             const float om = __shfl_xor(best, off);
             const int ok = __shfl_xor(bk, off);
-            if (om > best || (om == best && ok < bk)) { best = om; bk = ok; }
+            const bool tk = (om > best) | ((om == best) & (ok < bk));
+            best = tk ? om : best; bk = tk ? ok : bk;
         }
         if constexpr (TPF > 64) {
             if ((threadIdx.x & 63) == 0) { red_m[threadIdx.x >> 6] = best; red_k[threadIdx.x >> 6] = bk; }
