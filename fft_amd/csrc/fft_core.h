@@ -83,6 +83,11 @@ template <typename T, int R, typename C> __device__ __forceinline__ void bfly(C*
     else static_assert(R == 2 || R == 4 || R == 8 || R == 16, "unsupported radix");
 }
 
+// |X| of the fp32 kernels: the hardware square root (1 ulp) without libm's correctly-rounded fix-up sequence
+// (~8 instructions per output; the fp32 parity bar is 1e-5 log2 N).  fp64 keeps the exact sqrt.
+__device__ __forceinline__ float mag_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+__device__ __forceinline__ double mag_sqrt(double v) { return sqrt(v); }
+
 // LDS index with two-level padding: one pad element per 2^S elements and one more per 2^(2S).
 // Makes every power-of-two element stride conflict free for the wide DS reads (bank rows hold 2^S
 // elements: S=5 for 8-byte float2, S=4 for 16-byte double2).

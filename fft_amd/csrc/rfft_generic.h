@@ -144,8 +144,8 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                 const C wo = cmul(mk<T>(d.y, -d.x), tn[u]);
                 const C xa = cadd(e, wo);            // X[q]
                 const C xb = csub(e, wo);            // conj(X[M-q])
-                const T ma = sqrt(xa.x * xa.x + xa.y * xa.y);
-                const T mb = sqrt(xb.x * xb.x + xb.y * xb.y);
+                const T ma = mag_sqrt(xa.x * xa.x + xa.y * xa.y);
+                const T mb = mag_sqrt(xb.x * xb.x + xb.y * xb.y);
                 const int ka = q, kb = M - q;
                 if (wmag) { mf[ka] = out(ma); mf[kb] = out(mb); }
                 const bool ga = !(excl && ka == 0) && peak_better(ma, ka, best, best_k);
@@ -155,7 +155,7 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
             }
             if (tq == 0) {                           // bin M/2: X = conj(Z[M/2])
                 const C z = buf[lds_pad<S>(M / 2)];
-                const T m = sqrt(z.x * z.x + z.y * z.y);
+                const T m = mag_sqrt(z.x * z.x + z.y * z.y);
                 if (wmag) mf[M / 2] = out(m);
                 if (peak_better(m, M / 2, best, best_k)) { best = m; best_k = M / 2; }
             }

@@ -147,7 +147,7 @@ stft_stereo_kernel(StftArgs a) {
             auto emit = [&](int q, int voff, int soff, float2 zq, float2 zm) {
                 const float2 L = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
                 const float2 Rr = mk<float>(0.5f * (zq.y + zm.y), 0.5f * (zm.x - zq.x));
-                const float mL = sqrtf(L.x * L.x + L.y * L.y), mR = sqrtf(Rr.x * Rr.x + Rr.y * Rr.y);
+                const float mL = mag_sqrt(L.x * L.x + L.y * L.y), mR = mag_sqrt(Rr.x * Rr.x + Rr.y * Rr.y);
                 const float oL = DB ? 20.0f * log10f(fmaxf(mL, SA_DB_FLOOR_F32)) : mL;
                 const float oR = DB ? 20.0f * log10f(fmaxf(mR, SA_DB_FLOOR_F32)) : mR;
                 if constexpr (FPW == 1) {

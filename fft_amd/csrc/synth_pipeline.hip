@@ -166,12 +166,12 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
                 const float2 d = mk<float>(0.5f * (zq.x - zm.x), 0.5f * (zq.y + zm.y));
                 const float2 wo = cmul(mk<float>(d.y, -d.x), tn[u]);
                 const float2 xa = cadd(e, wo), xb = csub(e, wo);
-                consider(sqrtf(xa.x * xa.x + xa.y * xa.y), q, tq * 4, TPF * u * 4);
-                consider(sqrtf(xb.x * xb.x + xb.y * xb.y), M - q, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
+                consider(mag_sqrt(xa.x * xa.x + xa.y * xa.y), q, tq * 4, TPF * u * 4);
+                consider(mag_sqrt(xb.x * xb.x + xb.y * xb.y), M - q, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
             }
             if (tq == 0) {                                  // bin M/2: X = conj(Z[M/2])
                 const float2 z = buf[lds_pad<S>(M / 2)];
-                consider(sqrtf(z.x * z.x + z.y * z.y), M / 2, 0, (M / 2) * 4);
+                consider(mag_sqrt(z.x * z.x + z.y * z.y), M / 2, 0, (M / 2) * 4);
             }
         };
         if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});
