@@ -92,7 +92,7 @@ int dispatch_generic<float>(int log2n, const RfftArgs<float>& a, hipStream_t st)
         case 9: return generic_p16(true) ? launch_generic<float, 8, 16>(a, st) : launch_generic<float, 8, 8>(a, st);
         case 10: return generic_p16(false) ? launch_generic<float, 9, 16>(a, st) : launch_generic<float, 9, 8>(a, st);
         case 11: return generic_p16(true) ? launch_generic<float, 10, 16>(a, st) : launch_generic<float, 10, 8>(a, st);
-        case 12: return generic_p16(false) ? launch_generic<float, 11, 16>(a, st) : launch_generic<float, 11, 8>(a, st);
+        case 12: return generic_p16(true) ? launch_generic<float, 11, 16>(a, st) : launch_generic<float, 11, 8>(a, st);
         case 13: return generic_p16(true) ? launch_generic<float, 12, 16>(a, st) : launch_generic<float, 12, 8>(a, st);
         case 14: return generic_p16(true) ? launch_generic<float, 13, 16>(a, st) : launch_generic<float, 13, 8>(a, st);
         case 15: return launch_generic<float, 14, 16>(a, st);
