@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(MT) time_stats_wave_kernel(const T* __restrict
                 su = lane == 63 ? sign_class(nx[u]) : su;
                 const bool cr = (i + 1 < n) & (sv != su);
                 zc += cr;
-                zf = cr & (i < zf) ? i : zf;
+                zf = (cr & (i < zf)) ? i : zf;
                 zl = cr ? i : zl;
             }
         }
@@ -573,11 +573,11 @@ __global__ void __launch_bounds__(MT) spectral_metrics_wave_kernel(const T* __re
                     const double sq = dv * dv;
                     noise += (in & ((k < klo) | (k > khi))) ? sq : 0.0;
                     const bool hb = in & (dv >= half);
-                    blo = hb & (k < blo) ? k : blo;
+                    blo = (hb & (k < blo)) ? k : blo;
                     bhi = hb ? k : bhi;
                     const double fq = (double)k * freq_step;
                     const bool sb = in & (fq > f0 - side_hz) & (fq < f0 + side_hz);
-                    side = sb & (v > side) ? v : side;
+                    side = (sb & (v > side)) ? v : side;
                     if (in & (k > klo) & (k < khi) & (pv_[u] < v)) {   // a rise into k: peak if a strict fall follows the flat top
                         int j = k + 1;
                         T nv = nv_[u];

@@ -280,6 +280,31 @@ def spectral_metrics(mag_half, n, freq_step, side_hz=10.0):
     return out[0] if m.ndim == 1 else out
 
 
+def analyze_frames(x, fs, window="none", win_param=0.0, side_hz=10.0):
+    """Batch read-out in one call (sa_analyze_frames_f32 / _f64): x [batch, n] (or one frame) of float32 or
+    float64 records sampled at fs -> (time_stats, spec_metrics, peak_bin, peak_mag) per frame, the spectra
+    staying on the device.  The structs are the ones time_stats() / spectral_metrics() return, so the
+    reference's read-outs (Vpp, RMS, THD, SNR, SFDR, bandwidth ...) follow from them as in analysis_panels."""
+    import ctypes as C
+    from .batch import window_id
+    x = np.asarray(x)
+    one = x.ndim == 1
+    x = np.ascontiguousarray(x[None] if one else x, dtype=np.float32 if x.dtype == np.float32 else np.float64)
+    if x.ndim != 2:
+        raise ValueError("x must be one frame or a [batch, n] array")
+    batch, n = x.shape
+    ts = (_lib.TimeStats * max(batch, 1))()
+    sm = (_lib.SpecMetrics * max(batch, 1))()
+    pb = np.empty(batch, dtype=np.int32)
+    pm = np.empty(batch, dtype=x.dtype)
+    fn = _lib.load().sa_analyze_frames_f32 if x.dtype == np.float32 else _lib.load().sa_analyze_frames_f64
+    _lib.check(fn(_lib.ptr(x), batch, n, window_id(window), float(win_param), float(fs), float(side_hz),
+                  C.cast(ts, C.c_void_p), C.cast(sm, C.c_void_p), _lib.ptr(pb), _lib.ptr(pm)))
+    if one:
+        return ts[0], sm[0], int(pb[0]), float(pm[0])
+    return ts, sm, pb, pm
+
+
 def _zero_cross_freq(t, s):
     """(rate, freq_est) of main.py:1006-1014 from the device's crossing count and first/last crossing:
     np.mean(np.diff(t[zc])) telescopes to (t[zc[-1]] - t[zc[0]]) / (len(zc) - 1)."""

@@ -255,6 +255,26 @@ int sa_spectral_metrics_f32_dev(const float* mag, int64_t batch, int64_t n, doub
 int sa_spectral_metrics_f64_dev(const double* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
                                 sa_spec_metrics* out, void* stream);
 
+/* ---- whole read-out of a batch of records: what one "Calcular" does after synthesis (calculate_fft,
+ *      main.py:977-987 -> _calculate_time_analysis :989-1024 / update_analysis_panels :1542-1735), per frame --
+ * x [batch][n] -> window -> rfft -> |Y| on the device, then sa_time_stats over the frame and
+ * sa_spectral_metrics over its half spectrum (freq_step = fs/n); only the per-frame structs and the
+ * dominant peak cross PCIe (the spectra stay in device scratch).  n: power of two, 16..32768 (f32) /
+ * 16..16384 (f64).  ts, sm, peak_bin, peak_mag: [batch]; any of them may be NULL to skip that output.
+ * The _dev form takes device pointers; mag_work is batch*(n/2+1) elements of device scratch.  With mag_work,
+ * peak_bin and peak_mag all given it only queues work on `stream`; where one of them is NULL the library
+ * borrows the buffer from its per-thread arena and synchronises the stream before returning. */
+int sa_analyze_frames_f32(const float* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs,
+                          double side_hz, sa_time_stats* ts, sa_spec_metrics* sm, int32_t* peak_bin, float* peak_mag);
+int sa_analyze_frames_f64(const double* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs,
+                          double side_hz, sa_time_stats* ts, sa_spec_metrics* sm, int32_t* peak_bin, double* peak_mag);
+int sa_analyze_frames_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs,
+                              double side_hz, float* mag_work, sa_time_stats* ts, sa_spec_metrics* sm,
+                              int32_t* peak_bin, float* peak_mag, void* stream);
+int sa_analyze_frames_f64_dev(const double* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs,
+                              double side_hz, double* mag_work, sa_time_stats* ts, sa_spec_metrics* sm,
+                              int32_t* peak_bin, double* peak_mag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

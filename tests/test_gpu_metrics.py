@@ -202,6 +202,66 @@ def test_metrics_after_batched_rfft_device_resident():
         _check_spec_metrics(out[b], mag[b].astype(np.float64), n, step)
 
 
+@pytest.mark.parametrize("dtype,n,batch", [(np.float32, 4096, 70), (np.float32, 256, 300), (np.float64, 1024, 33),
+                                           (np.float32, 16384, 4100)])     # 4100 x 64 KiB: five upload chunks
+def test_analyze_frames_one_call(dtype, n, batch):
+    """sa_analyze_frames_*: the whole read-out in one call == the three separate entry points, bit for bit
+    (same kernels, the spectra just stay on the device), and == the oracle on a sample of frames."""
+    rng = np.random.default_rng(n + batch)
+    fs = 100e3
+    t = np.arange(n) / fs
+    f0 = rng.uniform(1000.0, 20000.0, size=(batch, 1))
+    x = (np.sin(2 * np.pi * f0 * t) + 0.25 * np.sin(2 * np.pi * 2 * f0 * t) + 0.01 * rng.standard_normal((batch, n))).astype(dtype)
+    ts, sm, pb, pm = S.analyze_frames(x, fs, "hann")
+    import fft_amd
+    mag, pb2, pm2 = fft_amd.rfft_peak(x, "hann")
+    np.testing.assert_array_equal(pb, pb2)
+    np.testing.assert_array_equal(pm, pm2)
+    sel = np.unique(np.r_[0, batch - 1, rng.integers(0, batch, 24)])
+    for b in sel:
+        _check_time_stats(ts[b], x[b].astype(np.float64))
+        _check_spec_metrics(sm[b], mag[b].astype(np.float64), n, fs / n)
+        mref = O.rfft_mag_peak(x[b][None], "hann")[0][0]                 # the fundamental the oracle's own spectrum gives
+        assert sm[b].fund_bin == int(np.argmax(mref[1:(n - 1) // 2 + 1])) + 1
+    one = S.analyze_frames(x[3], fs, "hann")
+    assert one[2] == pb[3] and one[1].fund_bin == sm[3].fund_bin and one[0].zc_count == ts[3].zc_count
+
+
+def test_analyze_frames_optional_outputs_and_errors():
+    lib = _lib.load()
+    x = np.random.default_rng(0).standard_normal((5, 64)).astype(np.float32)
+    ts = (_lib.TimeStats * 5)()
+    assert lib.sa_analyze_frames_f32(_lib.ptr(x), 5, 64, _lib.WIN_NONE, 0.0, 1e3, 10.0, C.cast(ts, C.c_void_p), None, None, None) == 0
+    for b in range(5):
+        _check_time_stats(ts[b], x[b].astype(np.float64))
+    pb = np.full(5, -1, np.int32)
+    assert lib.sa_analyze_frames_f32(_lib.ptr(x), 5, 64, _lib.WIN_NONE, 0.0, 1e3, 10.0, None, None, _lib.ptr(pb), None) == 0
+    np.testing.assert_array_equal(pb, O.rfft_mag_peak(x, "none")[1])
+    assert lib.sa_analyze_frames_f32(_lib.ptr(x), 5, 48, _lib.WIN_NONE, 0.0, 1e3, 10.0, None, None, _lib.ptr(pb), None) == _lib.SA_EUNSUP
+    assert lib.sa_analyze_frames_f32(_lib.ptr(x), 5, 8, _lib.WIN_NONE, 0.0, 1e3, 10.0, None, None, _lib.ptr(pb), None) == _lib.SA_EINVAL
+    assert lib.sa_analyze_frames_f32(_lib.ptr(x), 5, 64, _lib.WIN_NONE, 0.0, 0.0, 10.0, None, None, _lib.ptr(pb), None) == _lib.SA_EINVAL
+    assert lib.sa_analyze_frames_f64(None, 0, 64, _lib.WIN_NONE, 0.0, 1e3, 10.0, None, None, None, None) == 0
+    # device form with every buffer supplied by the caller
+    dx = _lib.DeviceBuffer(x.nbytes); dx.upload(x)
+    dm = _lib.DeviceBuffer(5 * 33 * 4)
+    dsm = _lib.DeviceBuffer(5 * C.sizeof(_lib.SpecMetrics))
+    dpb, dpm = _lib.DeviceBuffer(5 * 4), _lib.DeviceBuffer(5 * 4)
+    _lib.check(lib.sa_analyze_frames_f32_dev(dx.ptr, 5, 64, _lib.WIN_NONE, 0.0, 1e3, 10.0, dm.ptr, None, dsm.ptr, dpb.ptr, dpm.ptr, None))
+    _lib.check(lib.sa_sync())
+    out = (_lib.SpecMetrics * 5)()
+    _lib.check(lib.sa_memcpy_d2h(C.cast(out, C.c_void_p), dsm.ptr, C.sizeof(out)))
+    mag = np.empty((5, 33), np.float32); dm.download(mag)
+    for b in range(5):
+        _check_spec_metrics(out[b], mag[b].astype(np.float64), 64, 1e3 / 64)
+    # ... and with the library borrowing the scratch
+    _lib.check(lib.sa_analyze_frames_f32_dev(dx.ptr, 5, 64, _lib.WIN_NONE, 0.0, 1e3, 10.0, None, None, dsm.ptr, None, None, None))
+    out2 = (_lib.SpecMetrics * 5)()
+    _lib.check(lib.sa_memcpy_d2h(C.cast(out2, C.c_void_p), dsm.ptr, C.sizeof(out2)))
+    assert bytes(out) == bytes(out2)
+    for b in (dx, dm, dsm, dpb, dpm):
+        b.free()
+
+
 def test_metrics_argument_errors():
     lib = _lib.load()
     assert lib.sa_time_stats_f64(None, 1, 16, None) == _lib.SA_EINVAL

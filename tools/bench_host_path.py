@@ -25,4 +25,13 @@ for log2b in (12, 16, 18):
             best = min(best, time.perf_counter() - t0)
         res[f"2^{log2b} frames, {mode}"] = {"ms": best * 1e3, "M_spectra_per_s": batch / best / 1e6,
                                             "host_GB_per_s": (x.nbytes + (batch * (n // 2 + 1) * 4 if wm else 0)) / best / 1e9}
+    from fft_amd import specengine as S
+    S.analyze_frames(x[:256], 100e3, "hann")
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        S.analyze_frames(x, 100e3, "hann")
+        best = min(best, time.perf_counter() - t0)
+    res[f"2^{log2b} frames, analyze_frames (time stats + spectral metrics + peak)"] = {
+        "ms": best * 1e3, "M_frames_per_s": batch / best / 1e6, "host_GB_per_s": x.nbytes / best / 1e9}
 print(json.dumps(res, indent=1))
