@@ -46,7 +46,6 @@ struct C2cArgs {
     int conj_out;     // inverse transform: conjugate on store (last pass)
     double scale;     // 1/n for the inverse, else 1
     int natural;      // final pass: 1 = natural order, 0 = leave digit-reversed
-    int diag;
 };
 
 // ---- strided pass ------------------------------------------------------------------------------
@@ -62,51 +61,45 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
     Cd* buf = smem + col * LDSF;
     const int64_t groups_per_a = a.S / B;
     const int64_t ngroups = a.batch * a.A * groups_per_a;
-    // v holds the group being transformed, nx the next one: its loads are issued a whole iteration ahead (behind the
-    // two twiddle look-ups of the current group, so that waiting for those leaves them in flight — the memory
-    // counter retires in order).  The workgroup-wide barriers make every group as slow as its slowest load, and
-    // with rows 16 MiB apart (first pass of 2^30) that tail is long.
-    Cd v[P], nx[P];
-    auto load_group = [&](int64_t g, Cd* d) {
+    // v holds the group being transformed; once the transform's last LDS write is done v is dead, so the NEXT
+    // group's loads are issued into it before the twiddle/store epilogue and fly during it (no extra registers).
+    Cd v[P];
+    auto load_group = [&](int64_t g) {
         const int64_t sg = g % groups_per_a, ab = g / groups_per_a;
-        const int64_t base = (a.diag & 2) ? g * (R * B) + col : (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + sg * B + col;
-        const int64_t rs = (a.diag & 2) ? B : a.S;
+        const int64_t base = (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + sg * B + col;
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) d[u * R0 + n1] = a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * rs];
+            for (int n1 = 0; n1 < R0; ++n1) v[u * R0 + n1] = a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S];
     };
-    if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x, v);
+    if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x);
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int64_t sg = g % groups_per_a;
         const int64_t ab = g / groups_per_a;            // = batch * A + a
-        // twiddle w^{s k} (w = w_{RS}) for the store epilogue.  A thread's outputs are column c (s = sc), rows
-        // k = k0 + TPF u:  w^(sc k) = w^(sc k0) * (w^(sc TPF))^u.  Two table look-ups and a product tree of depth
-        // <= log2 P replace one look-up per output (2^30: 33.7 -> 31.0 ms).  Splitting w^(sc k0) further into wave-
-        // and column-uniform factors measured slower (32.6 ms): HBM traffic per pass is already the algorithmic
-        // 2 x 17.18 GB.
-        constexpr int NT = TPF * B;
-        constexpr int NU = (R * B) / NT;                 // outputs per thread (= P)
-        const int c = threadIdx.x % B, k0 = threadIdx.x / B;
-        const int64_t sc = sg * B + c;
-        const int64_t hm = ((int64_t)1 << a.h) - 1;
-        const int64_t j0 = sc * k0, j1 = sc * TPF;       // both < R * S
-        const Cd t0h = a.thi[j0 >> a.h], t0l = a.tlo[j0 & hm], t1h = a.thi[j1 >> a.h], t1l = a.tlo[j1 & hm];
-        const bool more = g + gridDim.x < ngroups;
-        if (more) load_group(g + gridDim.x, nx);
         if (a.conj_in) {
 #pragma unroll
             for (int i = 0; i < P; ++i) v[i].y = -v[i].y;
         }
         lds_fft<double, LR, C2C_PP, false>(v, buf, tl, a.twR);
-        const Cd w0 = cmul(t0h, t0l);
+        // twiddle w^{s k} (w = w_{RS}) and store, B contiguous columns per k.  A thread's outputs are column c
+        // (s = sc), rows k = k0 + TPF u:  w^(sc k) = w^(sc k0) * (w^(sc TPF))^u.  Two table look-ups (requested
+        // before the barrier that publishes the transform) and a product tree of depth <= log2 P replace one
+        // look-up per output (2^30: 33.7 -> 31.0 ms).  Splitting w^(sc k0) further into wave- and column-uniform
+        // factors measured slower (32.6 ms): HBM traffic per pass is already the algorithmic 2 x 17.18 GB.
+        constexpr int NT = TPF * B;
+        constexpr int NU = (R * B) / NT;                 // outputs per thread (= P)
+        const int c = threadIdx.x % B, k0 = threadIdx.x / B;
+        const int64_t sc = sg * B + c;
+        const int64_t hm = ((int64_t)1 << a.h) - 1;
+        auto lookup = [&](int64_t j) { return cmul(a.thi[j >> a.h], a.tlo[j & hm]); };   // j < R * S
+        const Cd w0 = lookup(sc * k0);
         Cd pw[5];                                        // d^(2^i), d = w^(sc TPF)
-        pw[0] = cmul(t1h, t1l);
+        pw[0] = lookup(sc * TPF);
         __syncthreads();
+        if (g + gridDim.x < ngroups) load_group(g + gridDim.x);
 #pragma unroll
         for (int i = 1; (1 << i) < NU; ++i) pw[i] = cmul(pw[i - 1], pw[i - 1]);
-        Cd* outp = (a.diag & 1) ? a.out + g * (R * B) + c : a.out + (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + sc;
-        const int64_t ws = (a.diag & 1) ? B : a.S;
+        Cd* outp = a.out + (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + sc;
         Cd bs[5];                                        // bs[t]: factor of the latest u with ctz(u) == t
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -119,11 +112,7 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
                 bs[t] = w;
             }
             const int k = k0 + TPF * u;
-            outp[(int64_t)k * ws] = cmul(smem[c * LDSF + lds_pad<S>(k)], w);
-        }
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) v[i] = nx[i];
+            outp[(int64_t)k * a.S] = cmul(smem[c * LDSF + lds_pad<S>(k)], w);
         }
         __syncthreads();
     }
@@ -298,9 +287,7 @@ int c2c_f64_dev(const double* in, double* out, double* work, int64_t n, int64_t 
     a.twR = tw_table(R1, R1, 1);
     if (!a.twR) return SA_EHIP;
     SA_TRY(set_pass_twiddles(a, n));
-    a.diag = getenv("SA_C2C_DIAG") ? atoi(getenv("SA_C2C_DIAG")) : 0;
     SA_TRY(run_strided(l1, a, st));
-    a.diag = 0;
     a.conj_in = 0;
     if (l3 == 0) {
         // final: rows of R2, A = R1 rows, natural index = k1 + R1 k2
