@@ -76,6 +76,7 @@ class Temp {
     size_t dmark_, hmark_;
     std::vector<void*> dextra_, hextra_;
 };
+int thread_state_count();
 void free_thread_caches();         // sa_shutdown: releases the cached blocks of every thread
 
 }  // namespace sa

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -14,7 +15,7 @@ namespace sa {
 
 static thread_local char g_err[512] = "";
 static std::mutex g_mu;
-static bool g_inited = false;
+static std::atomic<bool> g_inited{false};
 static int g_ncus = 256;
 
 void set_error(const char* fmt, ...) {
@@ -27,9 +28,9 @@ void set_error(const char* fmt, ...) {
 int num_cus() { return g_ncus; }
 
 int ensure_init() {
-    if (g_inited) return SA_OK;
+    if (g_inited.load(std::memory_order_acquire)) return SA_OK;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_inited) return SA_OK;
+    if (g_inited.load(std::memory_order_relaxed)) return SA_OK;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -46,28 +47,56 @@ int ensure_init() {
         return SA_ENODEV;
     }
     g_ncus = prop.multiProcessorCount;
-    g_inited = true;
+    g_inited.store(true, std::memory_order_release);
     return SA_OK;
 }
 
-// one stream per (host thread, device)
-struct ThreadStreams {
-    std::map<int, hipStream_t> s;
-    ~ThreadStreams() {
-        // Streams are intentionally not destroyed at thread exit: the HIP runtime may already be
-        // shutting down when thread_local destructors run.
+// ---- per-thread state: one stream per device and the temporary-memory cache (class Temp) ----------------
+// A thread's state outlives it: at thread exit it goes to a pool and the next new thread adopts it, so a program
+// that keeps starting short-lived threads holds as many streams and cached blocks as it ever had threads at once,
+// not one set per thread that ever lived.  Nothing is destroyed at thread exit (the HIP runtime may already be
+// shutting down when thread_local destructors run); sa_shutdown releases the cached blocks.
+struct ThreadCache {
+    int device = -1;
+    char* d = nullptr; size_t dcap = 0, doff = 0, dwant = 0;
+    char* h = nullptr; size_t hcap = 0, hoff = 0, hwant = 0;
+    int depth = 0;
+    std::map<int, hipStream_t> streams;
+};
+struct ThreadStatePool {                              // leaked on purpose: usable during static destruction
+    std::mutex mu;
+    std::vector<ThreadCache*> all, idle;
+};
+static ThreadStatePool& pool() {
+    static ThreadStatePool* p = new ThreadStatePool;
+    return *p;
+}
+struct ThreadCacheHolder {
+    ThreadCache* c;
+    ThreadCacheHolder() {
+        ThreadStatePool& p = pool();
+        std::lock_guard<std::mutex> l(p.mu);
+        if (!p.idle.empty()) { c = p.idle.back(); p.idle.pop_back(); }
+        else { c = new ThreadCache; p.all.push_back(c); }
+    }
+    ~ThreadCacheHolder() {
+        ThreadStatePool& p = pool();
+        std::lock_guard<std::mutex> l(p.mu);
+        c->depth = 0; c->doff = c->hoff = c->dwant = c->hwant = 0;
+        p.idle.push_back(c);
     }
 };
-static thread_local ThreadStreams g_streams;
+static thread_local ThreadCacheHolder t_cache;
 
 hipStream_t thread_stream() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    auto it = g_streams.s.find(dev);
-    if (it != g_streams.s.end()) return it->second;
+    std::map<int, hipStream_t>& m = t_cache.c->streams;
+    auto it = m.find(dev);
+    if (it != m.end()) return it->second;
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    g_streams.s[dev] = st;
+    m[dev] = st;
     return st;
 }
 
@@ -82,20 +111,6 @@ int allow_dynamic_lds(const void* kernel, int bytes, uint64_t* devs) {
 }
 
 // ---- per-thread temporary memory (class Temp) ---------------------------------------------------------
-struct ThreadCache {
-    int device = -1;
-    char* d = nullptr; size_t dcap = 0, doff = 0, dwant = 0;
-    char* h = nullptr; size_t hcap = 0, hoff = 0, hwant = 0;
-    int depth = 0;
-};
-static std::mutex g_cache_mu;
-static std::vector<ThreadCache*> g_caches;           // every thread's cache, for sa_shutdown
-struct ThreadCacheHolder {
-    ThreadCache* c;
-    ThreadCacheHolder() : c(new ThreadCache) { std::lock_guard<std::mutex> l(g_cache_mu); g_caches.push_back(c); }
-    // not freed at thread exit: the HIP runtime may already be gone; sa_shutdown releases the blocks
-};
-static thread_local ThreadCacheHolder t_cache;
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static void release_blocks(ThreadCache* c) {
@@ -171,9 +186,16 @@ void* Temp::pinned(size_t bytes) {
     return p;
 }
 
+int thread_state_count() {
+    ThreadStatePool& p = pool();
+    std::lock_guard<std::mutex> l(p.mu);
+    return (int)p.all.size();
+}
+
 void free_thread_caches() {
-    std::lock_guard<std::mutex> l(g_cache_mu);
-    for (ThreadCache* c : g_caches)
+    ThreadStatePool& p = pool();
+    std::lock_guard<std::mutex> l(p.mu);
+    for (ThreadCache* c : p.all)
         if (c->depth == 0) release_blocks(c);
 }
 
@@ -266,7 +288,7 @@ static int upload(const std::vector<double>& src, void** dptr) {
 const RfftPlan* get_rfft_plan(bool f64, int n, int window, double win_param) {
     int dev = 0;
     hipGetDevice(&dev);
-    if (window != SA_WIN_GAUSSIAN) win_param = 0;
+    if (window != SA_WIN_GAUSSIAN || !(win_param > 0)) win_param = 0;     // <= 0 or NaN: the default std (one plan, not one per call)
     PlanKey key(dev, f64, n, window, win_param);
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_plans.find(key);
@@ -377,6 +399,8 @@ int sa_memcpy_d2h(void* dst, const void* src, uint64_t bytes) {
     SA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return SA_OK;
 }
+int sa_thread_state_count(void) { return sa::thread_state_count(); }
+
 int sa_sync(void) {
     SA_TRY(sa::ensure_init());
     SA_HIP(hipStreamSynchronize(sa::thread_stream()));

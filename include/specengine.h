@@ -73,6 +73,10 @@ int  sa_dev_free(void* dptr);
 int  sa_memcpy_h2d(void* dst_dev, const void* src_host, uint64_t bytes);
 int  sa_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes);
 int  sa_sync(void);                       /* synchronise the calling thread's library stream */
+/* Number of per-thread state records (stream + staging cache) the library holds.  A record is handed to the next
+ * new thread when its thread exits, so this is the largest number of threads that ever used the library at the same
+ * time, not the number of threads that ever did.  Diagnostic; no reference counterpart. */
+int  sa_thread_state_count(void);
 
 /* ---- a6/a8/a9/a11: window -> real FFT -> |Y| (-> dB) -> dominant peak, batched ----------------
  * Replaces, per frame:  Y = fft(y*w); np.abs(Y); np.argmax(...)   (main.py:475, 479, 1029, 1627)

@@ -41,3 +41,27 @@ def test_concurrent_threads_match_serial():
             assert len(a) == len(b)
             for u, v in zip(a, b):
                 np.testing.assert_array_equal(u, v)
+
+
+def test_short_lived_threads_reuse_pooled_state():
+    """Threads that come and go: each new thread adopts the stream and staging cache an exited one left behind, so
+    the library's per-thread state stays bounded by the peak number of simultaneous threads."""
+    import threading
+    from fft_amd import _lib
+    lib = _lib.load()
+    x = np.random.default_rng(5).standard_normal((64, 1024)).astype(np.float32)
+    ref = fft_amd.rfft_peak(x, "hann")
+    results = []
+
+    def body():
+        results.append(fft_amd.rfft_peak(x, "hann"))
+
+    for _ in range(3):                                   # warm: at least one record exists and is idle again
+        th = threading.Thread(target=body); th.start(); th.join()
+    before = lib.sa_thread_state_count()
+    for _ in range(40):
+        th = threading.Thread(target=body); th.start(); th.join()
+    assert lib.sa_thread_state_count() == before
+    for r in results:
+        for u, v in zip(ref, r):
+            np.testing.assert_array_equal(u, v)
