@@ -4,6 +4,7 @@
 // Reference flow: on_calculate (main.py:512-560) -> calculate_fft (:977-987) -> the analysis panels
 // (:989-1053, :1542-1735).
 #include <math.h>
+#include <stdlib.h>
 
 #include "runtime.h"
 
@@ -31,6 +32,20 @@ template <> struct Entry<double> {
     static constexpr int32_t MAX_N = 16384;
 };
 
+// SA_ANALYZE_UNFUSED=1 (tuning / test aid) keeps the three-kernel chain for 4096-point fp32 frames too.
+template <typename T> static bool fused_4096(int32_t n) {
+    static const bool off = getenv("SA_ANALYZE_UNFUSED") != nullptr;
+    return sizeof(T) == 4 && n == 4096 && !off;
+}
+static int run_fused(const float* x, int64_t batch, int32_t window, double wp, int32_t* pb, float* pm, sa_time_stats* ts,
+                     sa_spec_metrics* sm, double fstep, double side, hipStream_t st) {
+    return rfft4096_metrics_dev(x, batch, window, wp, 0, nullptr, pb, pm, ts, sm, fstep, side, st);
+}
+static int run_fused(const double*, int64_t, int32_t, double, int32_t*, double*, sa_time_stats*, sa_spec_metrics*, double, double,
+                     hipStream_t) {
+    return SA_EUNSUP;                                   // never reached: fused_4096<double> is false
+}
+
 template <typename T>
 static int analyze_check(const T* x, int64_t batch, int32_t n, double fs) {
     if (batch < 0) { set_error("analyze_frames: batch must be >= 0 (got %lld)", (long long)batch); return SA_EINVAL; }
@@ -53,20 +68,28 @@ static int analyze_frames_dev(const T* x, int64_t batch, int32_t n, int32_t wind
     const int64_t nb = n / 2 + 1;
     Temp tmp;
     bool borrowed = false;                 // scratch taken from the thread's arena: synchronise before handing it back
-    if (sm && !mag_work) {
-        mag_work = static_cast<T*>(tmp.dev((size_t)batch * nb * sizeof(T)));
-        if (!mag_work) return SA_ENOMEM;
-        borrowed = true;
-    }
+    int32_t* pb = peak_bin;
+    T* pm = peak_mag;
     if (sm || peak_bin || peak_mag) {
-        int32_t* pb = peak_bin;
-        T* pm = peak_mag;
         if (!pb) { pb = static_cast<int32_t*>(tmp.dev((size_t)batch * sizeof(int32_t))); if (!pb) return SA_ENOMEM; borrowed = true; }
         if (!pm) { pm = static_cast<T*>(tmp.dev((size_t)batch * sizeof(T))); if (!pm) return SA_ENOMEM; borrowed = true; }
-        SA_TRY(Entry<T>::rfft(x, batch, n, window, win_param, sm ? SA_F_WRITE_MAG : 0, sm ? mag_work : nullptr, pb, pm, st));
     }
-    if (ts) SA_TRY(Entry<T>::tstats(x, batch, n, ts, st));
-    if (sm) SA_TRY(Entry<T>::smet(mag_work, batch, n, fs / n, side_hz, sm, st));
+    if (fused_4096<T>(n) && (ts || sm) && pb) {
+        // 4096-point fp32 frames whose transform is wanted anyway: statistics and metrics are computed inside the
+        // transform kernel, from the load registers and from the spectrum row in LDS — one read of the frames, no
+        // spectrum traffic at all
+        SA_TRY(run_fused(x, batch, window, win_param, pb, pm, ts, sm, fs / n, side_hz, st));
+    } else {
+        if (sm && !mag_work) {
+            mag_work = static_cast<T*>(tmp.dev((size_t)batch * nb * sizeof(T)));
+            if (!mag_work) return SA_ENOMEM;
+            borrowed = true;
+        }
+        if (sm || peak_bin || peak_mag)
+            SA_TRY(Entry<T>::rfft(x, batch, n, window, win_param, sm ? SA_F_WRITE_MAG : 0, sm ? mag_work : nullptr, pb, pm, st));
+        if (ts) SA_TRY(Entry<T>::tstats(x, batch, n, ts, st));
+        if (sm) SA_TRY(Entry<T>::smet(mag_work, batch, n, fs / n, side_hz, sm, st));
+    }
     if (borrowed) SA_HIP(hipStreamSynchronize(st));     // fully asynchronous only when the caller brings every buffer
     return SA_OK;
 }

@@ -17,6 +17,7 @@
 
 #include <vector>
 
+#include "metrics_row.h"
 #include "runtime.h"
 
 namespace sa {
@@ -379,38 +380,6 @@ __global__ void __launch_bounds__(MT) spectral_metrics_kernel(const T* __restric
 // Same results as the kernels above (selections are exact in either type: float -> double is monotone; sums are
 // fp64), about a quarter of the instructions: no 64-bit index bookkeeping, no fp64 compares for fp32 input, each
 // sample's sign class computed once and passed to the left neighbour with a lane shuffle.
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
-    return v;
-}
-// (value, index) argmax over the wave; LAST: among equal values keep the larger index, else the smaller
-template <typename T, bool LAST>
-__device__ __forceinline__ void wave_argmax(T& v, int& i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const T ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(i, off);
-        if (ov > v || (ov == v && (LAST ? oi > i : oi < i))) { v = ov; i = oi; }
-    }
-}
-template <typename T> __device__ __forceinline__ int sign_class(T v) { return (v > (T)0) - (v < (T)0); }
-
 template <typename T>
 __global__ void __launch_bounds__(MT) time_stats_wave_kernel(const T* __restrict__ y, int64_t batch, int n, int64_t stride,
                                                              sa_time_stats* __restrict__ out) {
@@ -504,105 +473,8 @@ __global__ void __launch_bounds__(MT) spectral_metrics_wave_kernel(const T* __re
                                                                    int64_t row_stride, double freq_step, double side_hz,
                                                                    sa_spec_metrics* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int K = (n - 1) / 2;
-    const T big = sizeof(T) == 4 ? (T)FLT_MAX : (T)DBL_MAX;
     for (int64_t row = (int64_t)blockIdx.x * MW + (threadIdx.x >> 6); row < batch; row += (int64_t)gridDim.x * MW) {
-        const T* m = mag_all + row * row_stride;
-        sa_spec_metrics r;
-        r.fund_bin = -1; r.harm_lo_bin = -1; r.n_peaks = 0; r.top_peak_bin = -1; r.bw_lo_bin = -1; r.bw_hi_bin = -1;
-        r.fund_amp = 0; r.harmonic_power = 0; r.max_spur = 0; r.noise_power = 0; r.total_power = 0; r.sideband_amp = 0;
-        double tp = 0;
-        T fa = -big;
-        int fk = 0;
-        constexpr int UNR = 8;                                  // loads of UNR sweeps in flight together
-        for (int k0 = 1; k0 <= K; k0 += 64 * UNR) {
-            T vv[UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int k = k0 + 64 * u + lane;
-                vv[u] = m[k <= K ? k : K];
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int k = k0 + 64 * u + lane;
-                const bool in = k <= K;
-                const double dv = in ? (double)vv[u] : 0.0;
-                tp = fma(2.0 * dv, dv, tp);
-                const bool g = in & (vv[u] > fa);
-                fa = g ? vv[u] : fa; fk = g ? k : fk;
-            }
-        }
-        tp = wave_sum(tp);
-        wave_argmax<T, false>(fa, fk);                          // np.argmax(Y_positive): first maximum (:1627)
-        tp += (double)m[0] * (double)m[0];
-        if (n >= 2 && n % 2 == 0) tp += (double)m[n / 2] * (double)m[n / 2];
-        r.total_power = tp;
-        if (K >= 1) {
-            const int k0 = fk;
-            const double A = (double)fa, f0 = (double)k0 * freq_step;
-            r.fund_bin = k0; r.fund_amp = A;
-            const double lim = f0 * 0.9;                        // harmonic mask (:1634): bins klo .. K-1
-            int klo = (int)floor(lim / freq_step) - 1;
-            if (klo < 1) klo = 1;
-            while (klo <= K && !((double)klo * freq_step > lim)) ++klo;
-            while (klo > 1 && (double)(klo - 1) * freq_step > lim) --klo;
-            if (klo > K) klo = K;
-            const int khi = K - 1;
-            r.harm_lo_bin = klo;
-            const double height = A * 0.05, half = A / sqrt(2.0);
-            // one sweep over the positive bins: peaks of m[klo..khi] >= 0.05 A (:1639), noise outside the mask
-            // (:1664), -3 dB band (:1691-1696), sidebands (:1717)
-            double hp = 0, noise = 0;
-            int np_ = 0, tk = -1, blo = INT32_MAX, bhi = -1;
-            T tv = -big, side = -big;
-            for (int kk = 1; kk <= K; kk += 64 * UNR) {
-                T vv[UNR], pv_[UNR], nv_[UNR];               // bin k, its left and right neighbours (clamped, unconditional loads)
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int k = kk + 64 * u + lane, kc = k <= K ? k : K;
-                    vv[u] = m[kc];
-                    pv_[u] = m[kc - 1];
-                    nv_[u] = m[kc + 1 <= K ? kc + 1 : K];
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int k = kk + 64 * u + lane;
-                    const bool in = k <= K;
-                    const T v = vv[u];
-                    const double dv = (double)v;
-                    const double sq = dv * dv;
-                    noise += (in & ((k < klo) | (k > khi))) ? sq : 0.0;
-                    const bool hb = in & (dv >= half);
-                    blo = (hb & (k < blo)) ? k : blo;
-                    bhi = hb ? k : bhi;
-                    const double fq = (double)k * freq_step;
-                    const bool sb = in & (fq > f0 - side_hz) & (fq < f0 + side_hz);
-                    side = (sb & (v > side)) ? v : side;
-                    if (in & (k > klo) & (k < khi) & (pv_[u] < v)) {   // a rise into k: peak if a strict fall follows the flat top
-                        int j = k + 1;
-                        T nv = nv_[u];
-                        while (j < khi && nv == v) { ++j; nv = m[j]; }
-                        if (nv < v) {
-                            const int mid = (k + (j - 1)) / 2;
-                            const T pv = m[mid];
-                            if ((double)pv >= height) {
-                                hp = fma((double)pv, (double)pv, hp); ++np_;
-                                if (pv > tv || (pv == tv && mid > tk)) { tv = pv; tk = mid; }
-                            }
-                        }
-                    }
-                }
-            }
-            hp = wave_sum(hp); noise = wave_sum(noise); np_ = wave_sum(np_);
-            blo = wave_min(blo); bhi = wave_max(bhi);
-            wave_argmax<T, true>(tv, tk);
-            int dummy = 0;
-            wave_argmax<T, false>(side, dummy);
-            r.harmonic_power = hp; r.n_peaks = np_; r.noise_power = noise;
-            r.sideband_amp = side == -big ? -DBL_MAX : (double)side;
-            if (np_ > 0) { r.max_spur = (double)tv; r.top_peak_bin = tk; }
-            if (bhi >= 0) { r.bw_lo_bin = blo; r.bw_hi_bin = bhi; }
-        }
+        const sa_spec_metrics r = spectral_metrics_row<T>(mag_all + row * row_stride, n, freq_step, side_hz, lane);
         if (lane == 0) out[row] = r;
     }
 }

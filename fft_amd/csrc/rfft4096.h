@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "fft_core.h"
+#include "metrics_row.h"
 
 namespace sa {
 
@@ -174,15 +175,113 @@ __device__ __forceinline__ void exch2_pass3(const float2 (&b0)[16], const float2
     stage_fence();
 }
 
+
+// ---- fused time statistics ("fused into the load pass") --------------------------------------------
+// The frame as load_frame leaves it: r[j][e] = x[256 j + 4 lane + e].  Same quantities as time_stats_wave_kernel
+// (metrics.hip) — sums and central moments in fp64, extrema / sign classes in fp32 — on data that is already in
+// registers, so the frame is read from HBM once for the transform and the statistics together.
+struct R4kFuse {
+    sa_time_stats* ts;        // [batch] or unused
+    sa_spec_metrics* sm;      // [batch] or unused
+    double freq_step, side_hz;
+};
+__device__ __forceinline__ float wave_fmax(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_fmin(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ sa_time_stats time_stats_regs4096(const v4f (&r)[16], int lane) {
+    constexpr int n = 4096;
+    double s1 = 0, s2 = 0;
+    float mx = -FLT_MAX, mn = FLT_MAX;
+    // Sample index i = 4 lane + 256 j + e.  Per load j the four crossing / equality flags are packed into a 4-bit
+    // mask, so the first / last hit of a lane costs a few bit operations per load instead of selects per sample
+    // (selects on 64 distinct index constants would park 64 constants in registers).
+    int zc = 0, zf = INT32_MAX, zl = -1;
+    int lo = lane;
+    asm volatile("" : "+v"(lo));                  // per-call opaque copy: nothing here is hoisted out of the frame loop
+    const int i4 = 4 * lo;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        // right neighbour of the quad's last sample: the next lane's first sample; lane 63 wraps to lane 0 of the
+        // next load, and the frame's last sample has none
+        float nxt = __shfl_down(r[j][0], 1);
+        const float wrap = j < 15 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[j < 15 ? j + 1 : j][0]), 0)) : 0.0f;
+        nxt = lo == 63 ? wrap : nxt;
+        int sc[5];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc[e] = sign_class(r[j][e]);
+        sc[4] = (j == 15) ? (lo == 63 ? sc[3] : sign_class(nxt)) : sign_class(nxt);    // no pair after the last sample
+        int m = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = r[j][e];
+            const double dv = (double)v;
+            s1 += dv;
+            s2 = fma(dv, dv, s2);
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+            m |= (sc[e] != sc[e + 1]) ? (1 << e) : 0;
+        }
+        zc += __popc(m);
+        const int fe = i4 + 256 * j + (__ffs(m) - 1), le = i4 + 256 * j + (31 - __clz(m));
+        zf = (m != 0 && zf == INT32_MAX) ? fe : zf;           // j grows along the loop: the first hit stays
+        zl = m != 0 ? le : zl;
+        __builtin_amdgcn_sched_barrier(0);                   // one load's worth of temporaries live at a time
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    mx = wave_fmax(mx); mn = wave_fmin(mn);
+    zc = wave_sum(zc); zf = wave_min(zf); zl = wave_max(zl);
+    const double mean = s1 / (double)n;
+    const double mid = ((double)mx + (double)mn) / 2;              // duty threshold, main.py:1592
+    double c2 = 0, c3 = 0, c4 = 0;
+    int above = 0, imx = INT32_MAX, imn = INT32_MAX;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        int mxm = 0, mnm = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = r[j][e];
+            asm volatile("" : "+v"(v));                      // opaque copy: else the 64 fp64 conversions of the first pass stay live
+            const double dv = (double)v;
+            const double d = dv - mean, d2 = d * d;
+            c2 += d2; c3 = c3 + d2 * d; c4 = c4 + d2 * d2;
+            above += dv > mid;
+            mxm |= (v == mx) ? (1 << e) : 0;
+            mnm |= (v == mn) ? (1 << e) : 0;
+        }
+        // first index of the extremum (np.argmax / np.argmin)
+        imx = (mxm != 0 && imx == INT32_MAX) ? i4 + 256 * j + (__ffs(mxm) - 1) : imx;
+        imn = (mnm != 0 && imn == INT32_MAX) ? i4 + 256 * j + (__ffs(mnm) - 1) : imn;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    c2 = wave_sum(c2); c3 = wave_sum(c3); c4 = wave_sum(c4); above = wave_sum(above);
+    imx = wave_min(imx); imn = wave_min(imn);
+    sa_time_stats t;
+    t.min = (double)mn; t.max = (double)mx; t.mean = mean; t.mean_sq = s2 / (double)n;
+    t.max_abs = (double)fmaxf(fabsf(mx), fabsf(mn));
+    t.m2 = c2 / (double)n; t.m3 = c3 / (double)n; t.m4 = c4 / (double)n;
+    t.zc_count = zc; t.zc_first = zc ? zf : -1; t.zc_last = zl;
+    t.above_mid = above; t.argmax = imx; t.argmin = imn;
+    return t;
+}
+
 // MODE: 0 = peak only, 1 = write |Y|, 2 = write dB
+// FUSE: bit 0 = time statistics of the frame (from the load registers), bit 1 = derived spectral metrics (from the
+//       spectrum row staged in the wave's slab; with MODE 0 the spectrum then never reaches HBM).  Not with MODE 2.
 // WAVES: waves per (persistent) workgroup = waves per CU.  PF: issue the next frame's 16 loads before the
 // Hermitian post-pass of the current one (needs ~64 more VGPRs, so it pairs with WAVES = 12).
-template <int MODE, int WAVES, bool PF>
+template <int MODE, int WAVES, bool PF, int FUSE = 0>
 __global__ void __launch_bounds__(WAVES * 64)
 rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_stride, const float* __restrict__ win,
                      const float2* __restrict__ twM, const float2* __restrict__ twN, int excl_dc_nyq,
                      float* __restrict__ mag, int32_t* __restrict__ peak_bin, float* __restrict__ peak_mag,
-                     float db_floor
+                     float db_floor, R4kFuse fuse
 #ifdef R4K_DIAG
                      , unsigned long long* diag_out
 #endif
@@ -191,6 +290,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
     unsigned long long diag_acc[R4K_NSTAMP] = {0}, diag_prev = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(diag_prev)::"memory");
 #endif
+    static_assert(!(MODE == 2 && (FUSE & 2)), "spectral metrics need the linear spectrum in the slab");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* wtab4 = reinterpret_cast<float4*>(smem_raw);                 // 1024 float4: 0.5 * window
     const int lane = threadIdx.x & 63;
@@ -241,6 +341,11 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         // the address VGPRs at one per access family (no 64-bit per-lane pointers).
         R4K_STAMP(0);                                   // [0] loop overhead / previous-frame tail
         if (!PF || frame == first) load_frame(frame);
+        if (FUSE & 1) {
+            const sa_time_stats t = time_stats_regs4096(r, lane);
+            if (lane == 0) fuse.ts[frame] = t;
+            stage_fence();
+        }
         // The base twiddles are made opaque once per frame: otherwise LICM hoists every derived power
         // (~140 registers of loop invariants) out of the frame loop and the allocator spills them.
         // Lane-derived addresses are re-derived from an opaque copy of the lane id at the stage that
@@ -311,7 +416,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
             const unsigned long long c = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(4095 - k);
             key = c > key ? c : key;
             if (MODE == 2) v = 20.0f * __log10f(fmaxf(v, db_floor));
-            if (MODE != 0) slabf[(kbase + o) + koff] = v;
+            if (MODE != 0 || (FUSE & 2)) slabf[(kbase + o) + koff] = v;
         };
         const float2 z0 = P1[0];
         {
@@ -381,6 +486,12 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
                 const int ke = l4 < 4 - o ? l4 : 2044 + l4;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(slabf[ke + o]), mrs, ke * 4, 0, 0);
             }
+        }
+        if (FUSE & 2) {
+            wave_lds_fence();
+            const sa_spec_metrics m = spectral_metrics_row<float>(slabf + o, 4096, fuse.freq_step, fuse.side_hz, lane);
+            if (lane == 0) fuse.sm[frame] = m;
+            wave_lds_fence();
         }
         R4K_STAMP(7);                                   // [7] Hermitian post-pass + stores
         // ---- dominant peak: lane-local best (packed key), then wave max of |Y| and lowest bin among

@@ -33,9 +33,9 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     return SA_OK;
 }
 
-template <int MODE, int WAVES, bool PF>
-static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st) {
-    auto kern = rfft4096_wave_kernel<MODE, WAVES, PF>;
+template <int MODE, int WAVES, bool PF, int FUSE = 0>
+static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st, const R4kFuse& fz = R4kFuse{}) {
+    auto kern = rfft4096_wave_kernel<MODE, WAVES, PF, FUSE>;
     constexpr int lds = r4k_lds_bytes(WAVES);
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
@@ -43,7 +43,7 @@ static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st) {
     const int64_t cap = num_cus();                    // persistent: one workgroup per CU
     const int grid = (int)(need < cap ? need : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, a.x, a.batch, a.frame_stride, a.win, a.twM, a.twN,
-                       (a.flags & SA_F_EXCLUDE_DC_NYQ) ? 1 : 0, a.mag, a.peak_bin, a.peak_mag, a.db_floor);
+                       (a.flags & SA_F_EXCLUDE_DC_NYQ) ? 1 : 0, a.mag, a.peak_bin, a.peak_mag, a.db_floor, fz);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
@@ -168,6 +168,41 @@ int rfft_peak_dev(const T* x, int64_t batch, int32_t n, int32_t window, double w
 template int rfft_peak_strided_dev<float>(const float*, int64_t, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);
 template int rfft_peak_dev<double>(const double*, int64_t, int32_t, int32_t, double, int32_t, double*, int32_t*, double*, hipStream_t);
 template int rfft_peak_dev<float>(const float*, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);
+
+// 4096-point fp32 frames with the derived metrics fused into the transform kernel (rfft4096.h, FUSE): time statistics
+// from the load registers, spectral metrics from the spectrum row in LDS.  mag may be NULL (flags without
+// SA_F_WRITE_MAG): the spectra then never reach HBM.  ts / sm: either may be NULL, not both.
+int rfft4096_metrics_dev(const float* x, int64_t batch, int32_t window, double win_param, int32_t flags, float* mag,
+                         int32_t* peak_bin, float* peak_mag, sa_time_stats* ts, sa_spec_metrics* sm, double freq_step,
+                         double side_hz, hipStream_t st) {
+    SA_TRY(ensure_init());
+    int log2n = 0;
+    SA_TRY(check_args(x, batch, 4096, window, flags, mag, peak_bin, peak_mag, &log2n));
+    if (flags & SA_F_DB) { set_error("fused metrics need the linear spectrum (SA_F_DB not allowed)"); return SA_EINVAL; }
+    if (!ts && !sm) { set_error("fused metrics: ts and sm are both NULL"); return SA_EINVAL; }
+    if (sm && (!(freq_step > 0) || !(freq_step < INFINITY))) { set_error("fused metrics: freq_step must be a positive finite number"); return SA_EINVAL; }
+    if (batch == 0) return SA_OK;
+    const RfftPlan* p = get_rfft_plan(false, 4096, window, win_param);
+    if (!p) return SA_EHIP;
+    RfftArgs<float> a;
+    a.x = x; a.batch = batch; a.frame_stride = 4096;
+    a.win = static_cast<const float*>(p->d_win);
+    a.twM = static_cast<const cplx<float>*>(p->d_twM);
+    a.twN = static_cast<const cplx<float>*>(p->d_twN);
+    a.flags = flags; a.mag = mag; a.peak_bin = peak_bin; a.peak_mag = peak_mag;
+    a.db_floor = (float)SA_DB_FLOOR_F32;
+    const R4kFuse fz{ts, sm, freq_step, side_hz};
+    const bool wmag = (flags & SA_F_WRITE_MAG) && mag;
+    const int fuse = (ts ? 1 : 0) | (sm ? 2 : 0);
+    if (wmag) {
+        if (fuse == 1) return launch_r4k_v<1, 16, false, 1>(a, st, fz);
+        if (fuse == 2) return launch_r4k_v<1, 16, false, 2>(a, st, fz);
+        return launch_r4k_v<1, 16, false, 3>(a, st, fz);
+    }
+    if (fuse == 1) return launch_r4k_v<0, 16, false, 1>(a, st, fz);
+    if (fuse == 2) return launch_r4k_v<0, 16, false, 2>(a, st, fz);
+    return launch_r4k_v<0, 16, false, 3>(a, st, fz);
+}
 
 // Host-pointer variant: stage through device memory in chunks, synchronise before returning.
 // One chunk: upload, kernel, download on the thread's stream.  Several chunks: a 3-deep pipeline — this thread

@@ -77,6 +77,9 @@ class Temp {
     std::vector<void*> dextra_, hextra_;
 };
 int thread_state_count();
+int rfft4096_metrics_dev(const float* x, int64_t batch, int32_t window, double win_param, int32_t flags, float* mag,
+                         int32_t* peak_bin, float* peak_mag, sa_time_stats* ts, sa_spec_metrics* sm, double freq_step,
+                         double side_hz, hipStream_t st);       // rfft_batch.hip: fused 4096-point fp32 kernel
 void free_thread_caches();         // sa_shutdown: releases the cached blocks of every thread
 
 }  // namespace sa

@@ -227,6 +227,68 @@ def test_analyze_frames_one_call(dtype, n, batch):
     assert one[2] == pb[3] and one[1].fund_bin == sm[3].fund_bin and one[0].zc_count == ts[3].zc_count
 
 
+def test_fused_4096_kernel_vs_chain_and_oracle():
+    """4096-point fp32 frames take the fused kernel (statistics from the load registers, metrics from the spectrum
+    row in LDS).  Against the three-kernel chain on the same device buffers: spectral metrics and peaks bit-identical
+    (same routine, same fp32 spectrum), time statistics equal in every integer / selected value and to 1e-12 in the
+    fp64 sums (different summation order); and both against the oracle.  Edge frames: constant, all-zero, impulse,
+    alternating sign, a frame whose extrema repeat."""
+    lib = _lib.load()
+    n, fs = 4096, 100e3
+    rng = np.random.default_rng(4096)
+    t = np.arange(n) / fs
+    f0 = rng.uniform(500.0, 45000.0, size=(90, 1))
+    x = (np.sin(2 * np.pi * f0 * t + rng.uniform(0, 6, (90, 1))) + 0.3 * np.sin(2 * np.pi * 3 * f0 * t)
+         + 0.02 * rng.standard_normal((90, n))).astype(np.float32)
+    x[0] = 0.75                                                        # constant
+    x[1] = 0.0                                                         # all zero: no crossings, no positive-bin peak
+    x[2] = 0.0; x[2, 777] = 1.0                                        # impulse: flat spectrum
+    x[3, ::2] = 1.0; x[3, 1::2] = -1.0                                 # Nyquist: a crossing at every sample
+    x[4] = np.sign(np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)  # square: extrema repeated, exact zeros
+    x[5, 4095] = 9.0; x[5, 0] = -9.0                                   # extrema at the frame's ends
+    batch = len(x)
+    dx = _lib.DeviceBuffer(x.nbytes); dx.upload(x)
+    dm = _lib.DeviceBuffer(batch * (n // 2 + 1) * 4)
+    bufs = [dx, dm]
+
+    def run(ts_on, sm_on, fused):
+        dts, dsm = _lib.DeviceBuffer(batch * C.sizeof(_lib.TimeStats)), _lib.DeviceBuffer(batch * C.sizeof(_lib.SpecMetrics))
+        dpb, dpm = _lib.DeviceBuffer(batch * 4), _lib.DeviceBuffer(batch * 4)
+        bufs.extend([dts, dsm, dpb, dpm])
+        if fused:
+            _lib.check(lib.sa_analyze_frames_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, fs, 10.0, dm.ptr,
+                                                     dts.ptr if ts_on else None, dsm.ptr if sm_on else None, dpb.ptr, dpm.ptr, None))
+        else:                                                          # the chain, entry point by entry point
+            _lib.check(lib.sa_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, _lib.F_WRITE_MAG, dm.ptr, dpb.ptr, dpm.ptr, None))
+            _lib.check(lib.sa_time_stats_f32_dev(dx.ptr, batch, n, n, dts.ptr, None))
+            _lib.check(lib.sa_spectral_metrics_f32_dev(dm.ptr, batch, n, fs / n, 10.0, dsm.ptr, None))
+        _lib.check(lib.sa_sync())
+        ts, sm = (_lib.TimeStats * batch)(), (_lib.SpecMetrics * batch)()
+        _lib.check(lib.sa_memcpy_d2h(C.cast(ts, C.c_void_p), dts.ptr, C.sizeof(ts)))
+        _lib.check(lib.sa_memcpy_d2h(C.cast(sm, C.c_void_p), dsm.ptr, C.sizeof(sm)))
+        pb, pm = np.empty(batch, np.int32), np.empty(batch, np.float32)
+        dpb.download(pb); dpm.download(pm)
+        return ts, sm, pb, pm
+
+    ts0, sm0, pb0, pm0 = run(True, True, fused=False)
+    mag = np.empty((batch, n // 2 + 1), np.float32); dm.download(mag)
+    for ts_on, sm_on in ((True, True), (True, False), (False, True)):
+        ts1, sm1, pb1, pm1 = run(ts_on, sm_on, fused=True)
+        np.testing.assert_array_equal(pb1, pb0)
+        np.testing.assert_array_equal(pm1, pm0)
+        if sm_on:
+            assert bytes(sm1) == bytes(sm0)
+        for b in range(batch):
+            if ts_on:
+                _check_time_stats(ts1[b], x[b].astype(np.float64))
+                for k in INT_FIELDS_T + ("min", "max", "max_abs"):
+                    assert getattr(ts1[b], k) == getattr(ts0[b], k), (b, k)
+            if sm_on:
+                _check_spec_metrics(sm1[b], mag[b].astype(np.float64), n, fs / n)
+    for b in bufs:
+        b.free()
+
+
 def test_analyze_frames_optional_outputs_and_errors():
     lib = _lib.load()
     x = np.random.default_rng(0).standard_normal((5, 64)).astype(np.float32)

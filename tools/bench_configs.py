@@ -135,6 +135,31 @@ def bench_metrics(log2_batch=20, n=4096):
             "spectral_metrics_GB_per_s_one_read": batch * (n // 2 + 1) * 4 / t2 / 1e9, "ms": t1 * 1e3}
 
 
+def bench_analyze(log2_batch=20, n=4096):
+    """Whole device-resident read-out at C2 size (sa_analyze_frames_f32_dev): frames -> time statistics + spectral
+    metrics + peak.  For 4096-point fp32 frames this is one fused kernel; SA_ANALYZE_UNFUSED=1 in the environment
+    times the three-kernel chain (rfft with spectra to scratch, time statistics, spectral metrics) instead."""
+    batch = 1 << log2_batch
+    x = torch.empty((batch, n), dtype=torch.float32, device="cuda")
+    _lib.check(lib.sa_fill_tone_noise_f32_dev(P(x), batch, n, 100e3, 0x5EED0002, CUR()))
+    mag = torch.empty((batch, n // 2 + 1), dtype=torch.float32, device="cuda")
+    ts = torch.empty(batch * C.sizeof(_lib.TimeStats), dtype=torch.uint8, device="cuda")
+    sm = torch.empty(batch * C.sizeof(_lib.SpecMetrics), dtype=torch.uint8, device="cuda")
+    pb = torch.empty(batch, dtype=torch.int32, device="cuda")
+    pm = torch.empty(batch, dtype=torch.float32, device="cuda")
+    res = {"config": f"analyze_frames at C2 size ({batch} x {n} fp32, Hann), device-resident",
+           "unfused_env": os.environ.get("SA_ANALYZE_UNFUSED") is not None}
+    for name, a_ts, a_sm in (("all", ts, sm), ("time_stats+peak", ts, None), ("spectral_metrics+peak", None, sm)):
+        run = lambda: _lib.check(lib.sa_analyze_frames_f32_dev(P(x), batch, n, _lib.WIN_HANN, 0.0, 100e3, 10.0, P(mag),
+                                                                P(a_ts) if a_ts is not None else None,
+                                                                P(a_sm) if a_sm is not None else None, P(pb), P(pm), CUR()))
+        dt = timeit(run, 5, 2)
+        res[name + "_ms"] = dt * 1e3
+        res[name + "_M_frames_per_s"] = batch / dt / 1e6
+    res["ms"] = res["all_ms"]
+    return res
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c4", "c5"]
     results = []
@@ -144,6 +169,8 @@ if __name__ == "__main__":
                 results.append(bench_rfft(1 << lg, dtype)); print(json.dumps(results[-1]), flush=True)
     if "metrics" in which:
         results.append(bench_metrics()); print(json.dumps(results[-1]), flush=True)
+    if "analyze" in which:
+        results.append(bench_analyze()); print(json.dumps(results[-1]), flush=True)
     if "stft" in which:
         for lg in range(8, 14):
             results.append(bench_c3(28, 1 << lg, (1 << lg) // 4)); print(json.dumps(results[-1]), flush=True)

@@ -19,7 +19,7 @@ int run(const char* name, float* dx, int64_t batch, float* dwin, float2* dtwM, f
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipMemset(ddiag, 0, 8 * R4K_NSTAMP));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), lds, 0, dx, batch, (int64_t)4096, dwin, dtwM, dtwN, 0, dmag, dpb, dpm, 1e-30f, ddiag);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), lds, 0, dx, batch, (int64_t)4096, dwin, dtwM, dtwN, 0, dmag, dpb, dpm, 1e-30f, R4kFuse{}, ddiag);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
     }
