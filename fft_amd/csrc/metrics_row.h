@@ -46,7 +46,7 @@ template <typename T> __device__ __forceinline__ int sign_class(T v) { return (v
 
 // Derived metrics of one half spectrum m[0 .. n/2] (|Y| of a length-n frame), all 64 lanes of a wave cooperating;
 // the returned struct is complete in every lane.  T = float or double; sums in fp64.
-template <typename T>
+template <typename T, int UNR = 8>
 __device__ __forceinline__ sa_spec_metrics spectral_metrics_row(const T* m, int n, double freq_step, double side_hz, int lane) {
     const int K = (n - 1) / 2;
     const T big = sizeof(T) == 4 ? (T)FLT_MAX : (T)DBL_MAX;
@@ -56,7 +56,7 @@ __device__ __forceinline__ sa_spec_metrics spectral_metrics_row(const T* m, int 
     double tp = 0;
     T fa = -big;
     int fk = 0;
-    constexpr int UNR = 8;                                  // loads of UNR sweeps in flight together
+    // UNR: loads of UNR sweeps in flight together (8 hides global-memory latency; LDS rows need less)
     for (int k0 = 1; k0 <= K; k0 += 64 * UNR) {
         T vv[UNR];
 #pragma unroll
