@@ -479,11 +479,43 @@ __global__ void __launch_bounds__(MT) spectral_metrics_wave_kernel(const T* __re
     }
 }
 
+// fp32 frames of 256 NL samples (NL = 1 .. 16) whose rows are 16-byte aligned: the frame is loaded once as NL
+// 16-byte loads per lane and both passes run on registers (time_stats_regs, metrics_row.h) — about half the
+// instructions of the sweep kernel above, and no second read.
+template <int NL>
+__global__ void __launch_bounds__(MT) time_stats_regs_kernel(const float* __restrict__ y, int64_t batch, int64_t stride,
+                                                             sa_time_stats* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t f = (int64_t)blockIdx.x * MW + (threadIdx.x >> 6); f < batch; f += (int64_t)gridDim.x * MW) {
+        const v4f* x4 = reinterpret_cast<const v4f*>(y + f * stride);
+        v4f r[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) r[j] = x4[64 * j + lane];
+        const sa_time_stats t = time_stats_regs<NL>(r, lane);
+        if (lane == 0) out[f] = t;
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------
 constexpr int64_t WAVE_ROW_MAX = 16384;      // frames up to this length: one wavefront per frame
 static unsigned grid_for(int64_t batch) {
     const int64_t cap = (int64_t)num_cus() * 8;
     return (unsigned)(batch < cap ? (batch < 1 ? 1 : batch) : cap);
+}
+
+// true when the register-resident kernel took the launch (fp32, n = 256 NL <= 4096, 16-byte aligned rows)
+static bool launch_regs_kernel(const double*, int64_t, int64_t, int64_t, sa_time_stats*, hipStream_t) { return false; }
+static bool launch_regs_kernel(const float* y, int64_t batch, int64_t n, int64_t stride, sa_time_stats* out, hipStream_t st) {
+    if ((reinterpret_cast<uintptr_t>(y) & 15) || (stride & 3)) return false;
+    const dim3 grid(grid_for((batch + MW - 1) / MW)), block(MT);
+    switch (n) {
+        case 256: hipLaunchKernelGGL(time_stats_regs_kernel<1>, grid, block, 0, st, y, batch, stride, out); return true;
+        case 512: hipLaunchKernelGGL(time_stats_regs_kernel<2>, grid, block, 0, st, y, batch, stride, out); return true;
+        case 1024: hipLaunchKernelGGL(time_stats_regs_kernel<4>, grid, block, 0, st, y, batch, stride, out); return true;
+        case 2048: hipLaunchKernelGGL(time_stats_regs_kernel<8>, grid, block, 0, st, y, batch, stride, out); return true;
+        case 4096: hipLaunchKernelGGL(time_stats_regs_kernel<16>, grid, block, 0, st, y, batch, stride, out); return true;
+    }
+    return false;
 }
 
 template <typename T>
@@ -492,7 +524,8 @@ static int time_stats_dev(const T* y, int64_t batch, int64_t n, int64_t stride, 
     if (batch < 0 || n < 1) { set_error("time_stats: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;
     if (!y || !out) { set_error("time_stats: NULL buffer"); return SA_EINVAL; }
-    if (n <= WAVE_ROW_MAX)        // batch path: one wavefront per frame, no barriers
+    if (launch_regs_kernel(y, batch, n, stride, out, st)) {
+    } else if (n <= WAVE_ROW_MAX)        // batch path: one wavefront per frame, no barriers
         hipLaunchKernelGGL(time_stats_wave_kernel<T>, dim3(grid_for((batch + MW - 1) / MW)), dim3(MT), 0, st, y, batch, (int)n, stride, out);
     else
         hipLaunchKernelGGL((time_stats_kernel<T, MT>), dim3(grid_for(batch)), dim3(MT), 0, st, y, batch, n, stride, out);

@@ -29,7 +29,6 @@
 
 namespace sa {
 
-typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int R4K_SLAB_BYTES = 8 * 136 * 8;         // 8704 B private exchange slab per wave
@@ -185,92 +184,6 @@ struct R4kFuse {
     sa_spec_metrics* sm;      // [batch] or unused
     double freq_step, side_hz;
 };
-__device__ __forceinline__ float wave_fmax(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ float wave_fmin(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ sa_time_stats time_stats_regs4096(const v4f (&r)[16], int lane) {
-    constexpr int n = 4096;
-    double s1 = 0, s2 = 0;
-    float mx = -FLT_MAX, mn = FLT_MAX;
-    // Sample index i = 4 lane + 256 j + e.  Per load j the four crossing / equality flags are packed into a 4-bit
-    // mask, so the first / last hit of a lane costs a few bit operations per load instead of selects per sample
-    // (selects on 64 distinct index constants would park 64 constants in registers).
-    int zc = 0, zf = INT32_MAX, zl = -1;
-    int lo = lane;
-    asm volatile("" : "+v"(lo));                  // per-call opaque copy: nothing here is hoisted out of the frame loop
-    const int i4 = 4 * lo;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        // right neighbour of the quad's last sample: the next lane's first sample; lane 63 wraps to lane 0 of the
-        // next load, and the frame's last sample has none
-        float nxt = __shfl_down(r[j][0], 1);
-        const float wrap = j < 15 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[j < 15 ? j + 1 : j][0]), 0)) : 0.0f;
-        nxt = lo == 63 ? wrap : nxt;
-        int sc[5];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sc[e] = sign_class(r[j][e]);
-        sc[4] = (j == 15) ? (lo == 63 ? sc[3] : sign_class(nxt)) : sign_class(nxt);    // no pair after the last sample
-        int m = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = r[j][e];
-            const double dv = (double)v;
-            s1 += dv;
-            s2 = fma(dv, dv, s2);
-            mx = fmaxf(mx, v);
-            mn = fminf(mn, v);
-            m |= (sc[e] != sc[e + 1]) ? (1 << e) : 0;
-        }
-        zc += __popc(m);
-        const int fe = i4 + 256 * j + (__ffs(m) - 1), le = i4 + 256 * j + (31 - __clz(m));
-        zf = (m != 0 && zf == INT32_MAX) ? fe : zf;           // j grows along the loop: the first hit stays
-        zl = m != 0 ? le : zl;
-        __builtin_amdgcn_sched_barrier(0);                   // one load's worth of temporaries live at a time
-    }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    mx = wave_fmax(mx); mn = wave_fmin(mn);
-    zc = wave_sum(zc); zf = wave_min(zf); zl = wave_max(zl);
-    const double mean = s1 / (double)n;
-    const double mid = ((double)mx + (double)mn) / 2;              // duty threshold, main.py:1592
-    double c2 = 0, c3 = 0, c4 = 0;
-    int above = 0, imx = INT32_MAX, imn = INT32_MAX;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        int mxm = 0, mnm = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = r[j][e];
-            asm volatile("" : "+v"(v));                      // opaque copy: else the 64 fp64 conversions of the first pass stay live
-            const double dv = (double)v;
-            const double d = dv - mean, d2 = d * d;
-            c2 += d2; c3 = c3 + d2 * d; c4 = c4 + d2 * d2;
-            above += dv > mid;
-            mxm |= (v == mx) ? (1 << e) : 0;
-            mnm |= (v == mn) ? (1 << e) : 0;
-        }
-        // first index of the extremum (np.argmax / np.argmin)
-        imx = (mxm != 0 && imx == INT32_MAX) ? i4 + 256 * j + (__ffs(mxm) - 1) : imx;
-        imn = (mnm != 0 && imn == INT32_MAX) ? i4 + 256 * j + (__ffs(mnm) - 1) : imn;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    c2 = wave_sum(c2); c3 = wave_sum(c3); c4 = wave_sum(c4); above = wave_sum(above);
-    imx = wave_min(imx); imn = wave_min(imn);
-    sa_time_stats t;
-    t.min = (double)mn; t.max = (double)mx; t.mean = mean; t.mean_sq = s2 / (double)n;
-    t.max_abs = (double)fmaxf(fabsf(mx), fabsf(mn));
-    t.m2 = c2 / (double)n; t.m3 = c3 / (double)n; t.m4 = c4 / (double)n;
-    t.zc_count = zc; t.zc_first = zc ? zf : -1; t.zc_last = zl;
-    t.above_mid = above; t.argmax = imx; t.argmin = imn;
-    return t;
-}
-
 // MODE: 0 = peak only, 1 = write |Y|, 2 = write dB
 // FUSE: bit 0 = time statistics of the frame (from the load registers), bit 1 = derived spectral metrics (from the
 //       spectrum row staged in the wave's slab; with MODE 0 the spectrum then never reaches HBM).  Not with MODE 2.
@@ -342,7 +255,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         R4K_STAMP(0);                                   // [0] loop overhead / previous-frame tail
         if (!PF || frame == first) load_frame(frame);
         if (FUSE & 1) {
-            const sa_time_stats t = time_stats_regs4096(r, lane);
+            const sa_time_stats t = time_stats_regs<16>(r, lane);
             if (lane == 0) fuse.ts[frame] = t;
             stage_fence();
         }

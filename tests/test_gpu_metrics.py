@@ -117,6 +117,36 @@ def test_time_stats_f32_device_batch():
         _check_time_stats(out[b], x[b * hop:b * hop + n].astype(np.float64))
 
 
+@pytest.mark.parametrize("n,stride", [(256, 256), (512, 512), (1024, 1028), (2048, 2048), (4096, 4096), (4096, 4097), (1024, 1022),
+                                      (8192, 8192), (300, 300)])
+def test_time_stats_f32_kernels_all_layouts(n, stride):
+    """fp32 device frames: 256 .. 4096 samples with 16-byte aligned rows take the register-resident kernel, everything
+    else (odd strides, other lengths) the sweep kernel; both against the oracle, with exact zeros, repeated extrema,
+    a constant frame and extrema at the ends in the batch."""
+    lib = _lib.load()
+    rng = np.random.default_rng(n * 31 + stride)
+    batch = 41
+    buf = rng.standard_normal((batch - 1) * stride + n).astype(np.float32)
+    buf[rng.integers(0, len(buf), size=len(buf) // 9)] = 0.0
+    frames = lambda: [buf[b * stride:b * stride + n] for b in range(batch)]
+    if stride >= n:                                                    # disjoint frames: plant the special cases
+        fr = frames()
+        fr[1][:] = 0.5
+        fr[2][:] = 0.0
+        fr[3][:] = np.where(np.arange(n) % 7 < 3, 1.0, -1.0)
+        fr[4][0] = 7.0; fr[4][n - 1] = -7.0
+        fr[5][n - 1] = 7.0; fr[5][0] = -7.0
+    dx = _lib.DeviceBuffer(buf.nbytes); dx.upload(buf)
+    dout = _lib.DeviceBuffer(batch * C.sizeof(_lib.TimeStats))
+    _lib.check(lib.sa_time_stats_f32_dev(dx.ptr, batch, n, stride, dout.ptr, None))
+    _lib.check(lib.sa_sync())
+    out = (_lib.TimeStats * batch)()
+    _lib.check(lib.sa_memcpy_d2h(C.cast(out, C.c_void_p), dout.ptr, C.sizeof(out)))
+    for b, f in enumerate(frames()):
+        _check_time_stats(out[b], f.astype(np.float64))
+    dx.free(); dout.free()
+
+
 @pytest.mark.parametrize("distance", [None, 1, 2, 3, 10, 57])
 def test_find_peaks_vs_scipy(distance):
     rng = np.random.default_rng(1234 + (distance or 0))
