@@ -62,6 +62,8 @@ PROTOTYPES = {
     "sa_spectral_metrics_f64": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp]),
     "sa_spectral_metrics_f32_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),
     "sa_spectral_metrics_f64_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),
+    "sa_cubic_upsample_f64": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "sa_cubic_upsample_f64_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "sa_analyze_frames_f32": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp]),
     "sa_analyze_frames_f64": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp]),
     "sa_analyze_frames_f32_dev": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -215,6 +215,37 @@ def synth_analyze(params, vpp=None, n_base=2048, upsample=8, window="gaussian", 
     return (mag, pb, pm, y) if return_signal else (mag, pb, pm)
 
 
+# ---- a10: smoothing of the zoomed time plot (main.py:1370-1397) -------------------------------------------
+INTERP_THRESHOLD = 100        # main.py:26
+INTERP_SAMPLES = 500          # main.py:27
+
+
+def cubic_upsample(t, y, n_out=INTERP_SAMPLES):
+    """(np.linspace(t[0], t[-1], n_out), CubicSpline(t, y)(that)) on the device (sa_cubic_upsample_f64), for one
+    row or a [batch, m] stack of rows — main.py:1390-1392.  Knots must be strictly increasing (ValueError)."""
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    if t.shape != y.shape or t.ndim not in (1, 2):
+        raise ValueError("The length of `y` along `axis`=0 doesn't match the length of `x`")
+    if t.shape[-1] < 2:
+        raise ValueError("`x` must contain at least 2 elements.")
+    batch = 1 if t.ndim == 1 else t.shape[0]
+    to = np.empty((batch, n_out), dtype=np.float64)
+    yo = np.empty((batch, n_out), dtype=np.float64)
+    _lib.check(_lib.load().sa_cubic_upsample_f64(_lib.ptr(t), _lib.ptr(y), batch, t.shape[-1], int(n_out), _lib.ptr(to), _lib.ptr(yo)))
+    return (to[0], yo[0]) if t.ndim == 1 else (to, yo)
+
+
+def time_zoom_data(last_data, x_lim):
+    """What SignalGeneratorApp.update_time_zoom hands to the time plot for the axis limits x_lim (main.py:1382-1397):
+    between 5 and 99 visible samples -> 500-point spline through them, else the raw record."""
+    t, y = np.asarray(last_data["t"]), np.asarray(last_data["y"])
+    vis = np.where((t >= x_lim[0]) & (t <= x_lim[1]))[0]
+    if 4 < len(vis) < INTERP_THRESHOLD:
+        return cubic_upsample(t[vis], y[vis], INTERP_SAMPLES)
+    return t, y
+
+
 # ---- derived metrics (SURVEY §8 f1/f2): the numbers come from the device, the strings are the reference's ----
 def format_freq(f):
     """SignalGeneratorApp._format_freq (main.py:1747-1755)."""

@@ -279,6 +279,17 @@ int sa_analyze_frames_f64_dev(const double* x, int64_t batch, int32_t n, int32_t
                               double side_hz, double* mag_work, sa_time_stats* ts, sa_spec_metrics* sm,
                               int32_t* peak_bin, double* peak_mag, void* stream);
 
+/* ---- a10: smoothing of the zoomed time plot (update_time_zoom, main.py:1385-1392; INTERP_THRESHOLD /
+ *      INTERP_SAMPLES main.py:26-27) -------------------------------------------------------------------------
+ * Per row: cs = scipy.interpolate.CubicSpline(t, y) (default not-a-knot ends; 2 knots: the line, 3 knots: the
+ * parabola, as scipy), t_out = np.linspace(t[0], t[-1], n_out), y_out = cs(t_out).  fp64; knots may be
+ * non-uniform but must be finite and strictly increasing (the host form checks and returns SA_EINVAL with
+ * scipy's message, the _dev form trusts the caller).  t, y: [batch][m], 2 <= m <= 2048; outputs [batch][n_out]. */
+int sa_cubic_upsample_f64(const double* t, const double* y, int64_t batch, int32_t m, int32_t n_out,
+                          double* t_out, double* y_out);
+int sa_cubic_upsample_f64_dev(const double* t, const double* y, int64_t batch, int32_t m, int32_t n_out,
+                              double* t_out, double* y_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

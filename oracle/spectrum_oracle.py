@@ -327,6 +327,17 @@ def cubic_spline_notaknot(xk, yk, xq):
     return ((c3[idx] * h + c2[idx]) * h + c1[idx]) * h + c0[idx]
 
 
+def time_zoom_data(last_data, x_lim, threshold=100, samples=500):
+    """Data SignalGeneratorApp.update_time_zoom draws for axis limits x_lim (main.py:1382-1397): 5 .. threshold-1
+    visible samples -> `samples`-point not-a-knot spline through them on np.linspace, else the raw record."""
+    t, y = np.asarray(last_data["t"]), np.asarray(last_data["y"])
+    vis = np.where((t >= x_lim[0]) & (t <= x_lim[1]))[0]
+    if 4 < len(vis) < threshold:
+        ti = np.linspace(t[vis][0], t[vis][-1], samples)
+        return ti, cubic_spline_notaknot(t[vis], y[vis], ti)
+    return t, y
+
+
 # ---- BASELINE config 3: STFT of PCM16 (north-star extension; oracle = strided np.fft.rfft frames) ----
 def stft_pcm16(pcm, nfft, hop, win="blackman", win_param=0.0, exclude_dc_nyq=False):
     """pcm int16 [n_samples, channels] -> (mag f64 [ch, frames, nfft/2+1], peak_bin [ch, frames], peak_mag).

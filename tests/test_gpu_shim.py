@@ -124,3 +124,46 @@ def test_compute_with_late_fork_fft_cap():
     assert np.abs(out["Y"] - ref["Y"]).max() <= 1e-12 * ref["Y"].max()
     full = S.compute(p, 2.0, max_points=S.ANALYSIS_MAX_POINTS)          # cap above N: the plain path
     assert len(full["Y"]) == 2000
+
+
+def test_time_zoom_matches_reference_update_time_zoom(golden_dir):
+    """a10 through the C ABI (sa_cubic_upsample_f64): the arrays the reference's update_time_zoom handed to the plot
+    (tests/golden/ref_zoom.npz, tools/gen_golden_zoom.py) — linspace abscissae bit-exact, spline values to 1e-12."""
+    z = np.load(os.path.join(golden_dir, "ref_zoom.npz"))
+    for i, rec in enumerate(z["case_record"]):
+        d = {"t": z[f"{rec}_t"], "y": z[f"{rec}_y"]}
+        t, y = S.time_zoom_data(d, z[f"c{i}_lim"])
+        np.testing.assert_array_equal(t, z[f"c{i}_t"])
+        np.testing.assert_allclose(y, z[f"c{i}_y"], rtol=0, atol=1e-12 * max(1.0, np.abs(z[f"c{i}_y"]).max()))
+
+
+def test_cubic_upsample_vs_scipy_fixture_and_oracle(golden_dir):
+    """CubicSpline(t, y)(np.linspace(...)): scipy's own outputs (ref_spline_zoom.npz), then non-uniform knots, the
+    2- and 3-knot special cases, a batch, and the largest supported row against the oracle."""
+    from oracle import spectrum_oracle as O
+    z = np.load(os.path.join(golden_dir, "ref_spline_zoom.npz"))
+    for n in (5, 6, 17, 64, 99):
+        ti, yi = S.cubic_upsample(z[f"k{n}_t"], z[f"k{n}_y"])
+        np.testing.assert_array_equal(ti, z[f"k{n}_ti"])
+        np.testing.assert_allclose(yi, z[f"k{n}_yi"], rtol=0, atol=2e-12)
+    rng = np.random.default_rng(10)
+    for m in (2, 3, 4, 5, 33, 100, 777, 2048):
+        t = np.cumsum(rng.uniform(0.1, 2.0, m)) * 1e-4 - 3.0                # non-uniform, strictly increasing
+        y = rng.standard_normal(m)
+        for n_out in (1, 2, 500, 1201):
+            ti, yi = S.cubic_upsample(t, y, n_out)
+            np.testing.assert_array_equal(ti, np.linspace(t[0], t[-1], n_out))
+            ref = O.cubic_spline_notaknot(t, y, ti)
+            assert np.abs(yi - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (m, n_out)   # dense solve vs Thomas: conditioning of random knots
+    tb = np.cumsum(rng.uniform(0.5, 1.5, (19, 40)), axis=1)
+    yb = rng.standard_normal((19, 40))
+    tib, yib = S.cubic_upsample(tb, yb, 300)
+    for b in range(19):
+        np.testing.assert_array_equal(tib[b], np.linspace(tb[b, 0], tb[b, -1], 300))
+        np.testing.assert_allclose(yib[b], O.cubic_spline_notaknot(tb[b], yb[b], tib[b]), rtol=0, atol=1e-11)
+    with pytest.raises(ValueError):
+        S.cubic_upsample([0.0, 1.0, 1.0, 2.0], [0.0, 1.0, 2.0, 3.0])          # scipy: `x` must be strictly increasing
+    with pytest.raises(ValueError):
+        S.cubic_upsample([0.0], [1.0])
+    with pytest.raises(ValueError):
+        S.cubic_upsample(np.arange(3000.0), np.zeros(3000))                  # beyond the supported knot count
