@@ -49,7 +49,14 @@ struct C2cArgs {
 };
 
 // ---- strided pass ------------------------------------------------------------------------------
-template <int LR, int B>
+// FAR = false: the next column group's loads are issued before the twiddle/store epilogue, into the butterfly
+//   registers, which are dead by then (no extra registers).
+// FAR = true (rows far apart, first pass of a 3-pass transform): the loads go out a whole transform earlier, into a
+//   second register set, and w_R sits in LDS (TwLds) so that nothing inside the transform waits on the vector-memory
+//   counter.  With one 128 KiB workgroup per CU nothing else covers the latency of 1024 x 128-byte reads 16 MiB
+//   apart: timing-only variants put that pass at 9.1 ms without the transform and 12.3 ms with it, while the
+//   second pass (rows 16 KiB apart) hides the same transform completely.
+template <int LR, int B, bool FAR>
 __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pass(C2cArgs a) {
     using PL = FftPlan<LR, C2C_PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
@@ -59,28 +66,36 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
     Cd* smem = reinterpret_cast<Cd*>(smem_raw);
     const int col = threadIdx.x % B, tl = threadIdx.x / B;
     Cd* buf = smem + col * LDSF;
+    Cd* twl = smem + B * LDSF;                       // FAR: w_R^i, i < R
+    if (FAR) {
+        for (int i = threadIdx.x; i < R; i += TPF * B) twl[i] = a.twR[i];
+        __syncthreads();
+    }
     const int64_t groups_per_a = a.S / B;
     const int64_t ngroups = a.batch * a.A * groups_per_a;
-    // v holds the group being transformed; once the transform's last LDS write is done v is dead, so the NEXT
-    // group's loads are issued into it before the twiddle/store epilogue and fly during it (no extra registers).
-    Cd v[P];
-    auto load_group = [&](int64_t g) {
+    Cd v[P], nx[FAR ? P : 1];
+    auto load_group = [&](int64_t g, Cd* d) {
         const int64_t sg = g % groups_per_a, ab = g / groups_per_a;
         const int64_t base = (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + sg * B + col;
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) v[u * R0 + n1] = a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S];
+            for (int n1 = 0; n1 < R0; ++n1) d[u * R0 + n1] = a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S];
     };
-    if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x);
+    if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x, v);
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int64_t sg = g % groups_per_a;
         const int64_t ab = g / groups_per_a;            // = batch * A + a
+        const bool more = g + gridDim.x < ngroups;
+        // unconditional (the last iteration re-reads its own group): a load under a branch would be waited for at the
+        // join, which is right here
+        if (FAR) load_group(more ? g + gridDim.x : g, nx);
         if (a.conj_in) {
 #pragma unroll
             for (int i = 0; i < P; ++i) v[i].y = -v[i].y;
         }
-        lds_fft<double, LR, C2C_PP, false>(v, buf, tl, a.twR);
+        if (FAR) lds_fft_tw<double, LR, C2C_PP, false>(v, buf, tl, TwLds<double>{twl});
+        else lds_fft<double, LR, C2C_PP, false>(v, buf, tl, a.twR);
         // twiddle w^{s k} (w = w_{RS}) and store, B contiguous columns per k.  A thread's outputs are column c
         // (s = sc), rows k = k0 + TPF u:  w^(sc k) = w^(sc k0) * (w^(sc TPF))^u.  Two table look-ups (requested
         // before the barrier that publishes the transform) and a product tree of depth <= log2 P replace one
@@ -96,7 +111,7 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
         Cd pw[5];                                        // d^(2^i), d = w^(sc TPF)
         pw[0] = lookup(sc * TPF);
         __syncthreads();
-        if (g + gridDim.x < ngroups) load_group(g + gridDim.x);
+        if (!FAR && more) load_group(g + gridDim.x, v);
 #pragma unroll
         for (int i = 1; (1 << i) < NU; ++i) pw[i] = cmul(pw[i - 1], pw[i - 1]);
         Cd* outp = a.out + (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + sc;
@@ -114,14 +129,18 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
             const int k = k0 + TPF * u;
             outp[(int64_t)k * a.S] = cmul(smem[c * LDSF + lds_pad<S>(k)], w);
         }
+        if (FAR) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i] = nx[i];
+        }
         __syncthreads();
     }
 }
 
 // ---- final (contiguous rows) pass ------------------------------------------------------------------
-template <int LR, int B>
-__global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_final_pass(C2cArgs a) {
-    using PL = FftPlan<LR, C2C_PP>;
+template <int LR, int B, int PP = C2C_PP>
+__global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * B)) c2c_final_pass(C2cArgs a) {
+    using PL = FftPlan<LR, PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
     constexpr int LDSF = lds_fft_elems<double, LR>();
     constexpr int S = LdsPadShift<double>::value;
@@ -150,7 +169,7 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_final_pass
 #pragma unroll
             for (int i = 0; i < P; ++i) v[i].y = -v[i].y;
         }
-        lds_fft<double, LR, C2C_PP>(v, buf, tl, a.twR);
+        lds_fft<double, LR, PP>(v, buf, tl, a.twR);
         if (g + gridDim.x < ngroups) load_group(g + gridDim.x);
         constexpr int NT = TPF * B;
 #pragma unroll
@@ -181,10 +200,11 @@ static const Cd* tw_table(int64_t n, int64_t count, int64_t stride) {
     return static_cast<const Cd*>(get_cached_table(key, (size_t)count * 16, fill_tw, &c));
 }
 
-template <int LR, int B>
+template <int LR, int B, bool FAR = false>
 static int launch_strided(C2cArgs a, hipStream_t st) {
-    constexpr int lds = lds_fft_elems<double, LR>() * B * 16;
-    auto kern = c2c_strided_pass<LR, B>;
+    constexpr int lds = lds_fft_elems<double, LR>() * B * 16 + (FAR ? (16 << LR) : 0);
+    static_assert(lds <= 160 * 1024, "strided pass does not fit LDS");
+    auto kern = c2c_strided_pass<LR, B, FAR>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t ngroups = a.batch * a.A * (a.S / B);
@@ -193,20 +213,28 @@ static int launch_strided(C2cArgs a, hipStream_t st) {
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
-template <int LR, int B>
+template <int LR, int B, int PP = C2C_PP>
 static int launch_final(C2cArgs a, hipStream_t st) {
     constexpr int lds = lds_fft_elems<double, LR>() * B * 16;
-    auto kern = c2c_final_pass<LR, B>;
+    auto kern = c2c_final_pass<LR, B, PP>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t ngroups = a.batch * (a.A / B);
     const int64_t cap = (int64_t)num_cus() * 16;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR, C2C_PP>::TPF * B), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR, PP>::TPF * B), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
 
+// FAR variant for the radix-1024 and radix-512 passes of long transforms (every workgroup then loops over several
+// column groups, which is what the early loads pay off on; measured 2^27: 3.24 -> 3.06 ms, 2^29: 14.7 -> 13.9 ms,
+// first two passes of 2^30: 13.2 + 9.1 -> 12.5 + 8.4 ms; short transforms lose a few percent to its set-up).
+// SA_C2C_FAR (tuning aid): bit 0 = radix 1024, bit 1 = radix 512; default both.
 static int run_strided(int lr, const C2cArgs& a, hipStream_t st) {
+    static const int far_env = getenv("SA_C2C_FAR") ? atoi(getenv("SA_C2C_FAR")) : 3;
+    const int far = a.batch * a.A * (a.S / 8) >= 8 * (int64_t)num_cus() ? far_env : 0;
+    if (lr == 10 && (far & 1)) return launch_strided<10, 8, true>(a, st);
+    if (lr == 9 && (far & 2)) return launch_strided<9, 8, true>(a, st);
     switch (lr) {
         case 6: return launch_strided<6, 8>(a, st);
         case 7: return launch_strided<7, 8>(a, st);
@@ -218,6 +246,10 @@ static int run_strided(int lr, const C2cArgs& a, hipStream_t st) {
     return SA_EUNSUP;
 }
 static int run_final_multi(int lr, const C2cArgs& a, hipStream_t st) {
+    // 1024-point rows: 16 points per thread (512 threads, 208 VGPRs) measured 8.7 -> 7.8 ms at 2^30; 512-point rows
+    // gain nothing from it.  SA_C2C_FINAL_PP16=0 (tuning aid) turns it off.
+    static const int pp16 = getenv("SA_C2C_FINAL_PP16") ? atoi(getenv("SA_C2C_FINAL_PP16")) : 1;
+    if (lr == 10 && (pp16 & 1) && a.batch * (a.A / 8) >= 8 * (int64_t)num_cus()) return launch_final<10, 8, 16>(a, st);
     switch (lr) {
         case 6: return launch_final<6, 8>(a, st);
         case 7: return launch_final<7, 8>(a, st);

@@ -73,6 +73,13 @@ template <typename T> struct TwGlobal {
     const cplx<T>* __restrict__ twR;     // w_R^i, i < R
     template <int J, int HPREV, int MJ> __device__ __forceinline__ cplx<T> get(int id) const { return twR[HPREV * (id % MJ)]; }
 };
+// TwLds: the table sits in LDS.  Its reads are counted with the LDS operations, not with the vector-memory loads,
+// so a kernel can keep global loads in flight across the transform (the memory counter retires in order: waiting
+// for a table load from global memory would also wait for every load issued before it).
+template <typename T> struct TwLds {
+    const cplx<T>* twR;                  // w_R^i, i < R, in LDS
+    template <int J, int HPREV, int MJ> __device__ __forceinline__ cplx<T> get(int id) const { return twR[HPREV * (id % MJ)]; }
+};
 template <typename T, int LR, int PP = 8> struct TwRegs {
     using PL = FftPlan<LR, PP>;
     static_assert(PL::NP == 1 || PL::P == PL::radix(0), "one butterfly per thread in the twiddled passes");
