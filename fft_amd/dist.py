@@ -4,7 +4,8 @@ Two sharding patterns, as SURVEY §8(e):
 
 1. Independent frames (batched rfft+peak, STFT, fused generator pipeline) shard by contiguous frame
    blocks with NO data-path collective; the only exchange is an optional gather of the 8-byte
-   (peak_bin, peak_mag) records.  `shard_range` is the single source of truth for the partition.
+   (peak_bin, peak_mag) records.  `shard_range` is the single source of truth for the partition;
+   `stft_shard` adds the sample span (with its nfft - hop halo) a rank's STFT frames need.
 
 2. One huge complex FFT (BASELINE config 5) = distributed four-step with ONE all-to-all:
        view x as [N1][N2] row-major (n = n1*N2 + n2); rank r owns columns n2 in [r*N2/P, (r+1)*N2/P)
@@ -51,6 +52,37 @@ def gather_peaks(peak_bin, peak_mag, group=None, dst=0):
     bins = torch.cat([o[:s, 0] for o, s in zip(out, sizes)]).to(torch.int32)
     mags = torch.cat([o[:s, 1] for o, s in zip(out, sizes)])
     return bins, mags
+
+
+def stft_shard(n_samples, nfft, hop, rank, world):
+    """STFT frames shard like any other frames: rank `rank` owns frames [f_lo, f_hi) of the
+    (n_samples - nfft)//hop + 1 frames and must be fed samples [s_lo, s_hi) = [f_lo*hop, (f_hi-1)*hop + nfft): its
+    own hop-sized steps plus a halo of nfft - hop samples that the next rank also reads.  The halo comes from the
+    source (host file / capture buffer), never from a neighbour GPU.  Returns (f_lo, f_hi, s_lo, s_hi); an empty
+    shard has f_lo == f_hi and s_lo == s_hi."""
+    nf = (int(n_samples) - int(nfft)) // int(hop) + 1 if n_samples >= nfft else 0
+    f_lo, f_hi = shard_range(nf, rank, world)
+    if f_hi == f_lo:
+        return f_lo, f_hi, f_lo * hop, f_lo * hop
+    return f_lo, f_hi, f_lo * hop, (f_hi - 1) * hop + nfft
+
+
+def stft_pcm16_sharded(pcm, nfft=8192, hop=2048, window="blackman", win_param=0.0, write_mag=True, db=False,
+                       exclude_dc_nyq=False, rank=None, world=None):
+    """This rank's part of fft_amd.stft_pcm16(pcm, ...): slices its sample span (stft_shard) out of `pcm` — an
+    array or np.memmap of the whole recording, only the span is touched — and runs it on this process' GPU.
+    Returns (f_lo, f_hi, mag, peak_bin, peak_mag) with the frame axis covering [f_lo, f_hi); stacking the ranks'
+    results along the frame axis in rank order gives exactly the single-GPU result.  No collective."""
+    from .batch import stft_pcm16
+    if rank is None or world is None:
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+    f_lo, f_hi, s_lo, s_hi = stft_shard(len(pcm), nfft, hop, rank, world)
+    span = np.ascontiguousarray(pcm[s_lo:s_hi])
+    if f_hi == f_lo:
+        span = np.zeros((0,) + tuple(np.shape(pcm)[1:]), dtype=np.int16)
+    mag, pb, pm = stft_pcm16(span, nfft, hop, window, win_param, write_mag, db, exclude_dc_nyq)
+    return f_lo, f_hi, mag, pb, pm
 
 
 # ---- local engines ---------------------------------------------------------------------------------

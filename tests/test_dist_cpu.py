@@ -5,11 +5,35 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from fft_amd import dist as D
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stft_shard_spans_and_halo():
+    """Frame ranges partition the frames; every rank's sample span holds exactly its frames (halo included): frame f
+    of the whole recording == frame f - f_lo of the span, sample for sample."""
+    from fft_amd.dist import stft_shard
+    rng = np.random.default_rng(0)
+    for ns, nfft, hop in ((100_000, 8192, 2048), (8192, 8192, 2048), (8191, 8192, 2048), (50_000, 1024, 1024), (33_333, 256, 64),
+                          (20_000, 4096, 4096 + 512)):
+        x = rng.integers(-32768, 32767, ns, dtype=np.int16)
+        nf = (ns - nfft) // hop + 1 if ns >= nfft else 0
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for rank in range(world):
+                f_lo, f_hi, s_lo, s_hi = stft_shard(ns, nfft, hop, rank, world)
+                assert f_lo == nxt and f_hi >= f_lo
+                nxt = f_hi
+                span = x[s_lo:s_hi]
+                assert len(span) == (0 if f_hi == f_lo else (f_hi - f_lo - 1) * hop + nfft) and s_hi <= ns
+                assert ((len(span) - nfft) // hop + 1 if len(span) >= nfft else 0) == f_hi - f_lo
+                for f in {f_lo, (f_lo + f_hi) // 2, f_hi - 1} if f_hi > f_lo else ():
+                    np.testing.assert_array_equal(x[f * hop:f * hop + nfft], span[(f - f_lo) * hop:(f - f_lo) * hop + nfft])
+            assert nxt == nf
 
 
 def test_shard_range_partitions():
