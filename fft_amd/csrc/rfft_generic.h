@@ -78,6 +78,9 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
 #pragma unroll
             for (int i = 0; i < P; ++i) w[i] = mk<T>(1, 1);
         }
+        // the 1/2 of the Hermitian split rides on the window (exact: a power of two)
+#pragma unroll
+        for (int i = 0; i < P; ++i) { w[i].x *= (T)0.5; w[i].y *= (T)0.5; }
 #pragma unroll
         for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tl + TPF * u];
     }
@@ -135,14 +138,23 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
         auto epilogue = [&](auto DBT) {
             constexpr bool DB = decltype(DBT)::value;
             auto out = [&](T m) { return DB ? (T)20 * log10(fmax(m, a.db_floor)) : m; };
+            // Padded LDS addresses are additive over disjoint bit fields (lds_fft.h): Z[q], q = tq + TPF u, sits at
+            // pad(tq) + pad(TPF u); its mirror M - q = (M - TPF (u+1)) + (TPF - tq) at pad(TPF - tq) + a constant for
+            // every lane but tq = 0 (whose mirror M - TPF u is a constant itself) — one select instead of a
+            // subtract / mask / shift / add chain per access.
+            const C* pq = buf + lds_pad<S>(tq);
+            const int mlow = lds_pad<S>(TPF - tq);
+            constexpr T HALF = HOIST ? (T)1 : (T)0.5;        // fp32: already in the window
 #pragma unroll
             for (int u = 0; u < NIT; ++u) {
                 const int q = tq + TPF * u;
-                const C zq = buf[lds_pad<S>(q)];
-                const C zm = buf[lds_pad<S>((M - q) & (M - 1))];
+                const int moff = lds_pad_c<S>(M - TPF * (u + 1));
+                const int m0 = lds_pad_c<S>((M - TPF * u) & (M - 1)) - moff;       // what tq = 0 needs in place of mlow
+                const C zq = pq[lds_pad_c<S>(TPF * u)];
+                const C zm = buf[(tq == 0 ? m0 : mlow) + moff];
                 // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
-                const C e = mk<T>((T)0.5 * (zq.x + zm.x), (T)0.5 * (zq.y - zm.y));
-                const C d = mk<T>((T)0.5 * (zq.x - zm.x), (T)0.5 * (zq.y + zm.y));
+                const C e = mk<T>(HALF * (zq.x + zm.x), HALF * (zq.y - zm.y));
+                const C d = mk<T>(HALF * (zq.x - zm.x), HALF * (zq.y + zm.y));
                 const C wo = cmul(mk<T>(d.y, -d.x), tn[u]);
                 const C xa = cadd(e, wo);            // X[q]
                 const C xb = csub(e, wo);            // conj(X[M-q])
@@ -156,8 +168,8 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                 best = gb ? mb : best; best_k = gb ? kb : best_k;
             }
             if (tq == 0) {                           // bin M/2: X = conj(Z[M/2])
-                const C z = buf[lds_pad<S>(M / 2)];
-                const T m = mag_sqrt(z.x * z.x + z.y * z.y);
+                const C z = buf[lds_pad_c<S>(M / 2)];
+                const T m = (HOIST ? (T)2 : (T)1) * mag_sqrt(z.x * z.x + z.y * z.y);
                 if (wmag) mf[M / 2] = out(m);
                 if (peak_better(m, M / 2, best, best_k)) { best = m; best_k = M / 2; }
             }

@@ -70,7 +70,8 @@ stft_stereo_kernel(StftArgs a) {
     const bool excl = a.flags & SA_F_EXCLUDE_DC_NYQ;
     constexpr int NB = N / 2 + 1;
     // Per-thread constants of the whole launch: every thread handles the same positions of every frame,
-    // so its window samples (pre-scaled by 1/32768) and FFT twiddles live in registers; inside the frame
+    // so its window samples (pre-scaled by 1/32768, and by the 1/2 of the channel split — exact, a power of two)
+    // and FFT twiddles live in registers; inside the frame
     // loop the only global loads are the PCM words, and those of the NEXT frame are in flight while this
     // frame is transformed.
     float w[P];
@@ -78,10 +79,10 @@ stft_stereo_kernel(StftArgs a) {
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) w[u * R0 + n1] = a.win[n1 * (N / R0) + TPF * u + tl] * (1.0f / 32768.0f);
+            for (int n1 = 0; n1 < R0; ++n1) w[u * R0 + n1] = a.win[n1 * (N / R0) + TPF * u + tl] * (0.5f / 32768.0f);
     } else {
 #pragma unroll
-        for (int i = 0; i < P; ++i) w[i] = 1.0f / 32768.0f;
+        for (int i = 0; i < P; ++i) w[i] = 0.5f / 32768.0f;
     }
     TwRegs<float, LR, PP> tw;
     tw.load(a.twR, tl);
@@ -145,8 +146,8 @@ stft_stereo_kernel(StftArgs a) {
         auto epilogue = [&](auto DBT) {
             constexpr bool DB = decltype(DBT)::value;
             auto emit = [&](int q, int voff, int soff, float2 zq, float2 zm) {
-                const float2 L = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
-                const float2 Rr = mk<float>(0.5f * (zq.y + zm.y), 0.5f * (zm.x - zq.x));
+                const float2 L = mk<float>(zq.x + zm.x, zq.y - zm.y);          // the 1/2 is in the window
+                const float2 Rr = mk<float>(zq.y + zm.y, zm.x - zq.x);
                 const float mL = mag_sqrt(L.x * L.x + L.y * L.y), mR = mag_sqrt(Rr.x * Rr.x + Rr.y * Rr.y);
                 const float oL = DB ? 20.0f * log10f(fmaxf(mL, SA_DB_FLOOR_F32)) : mL;
                 const float oR = DB ? 20.0f * log10f(fmaxf(mR, SA_DB_FLOOR_F32)) : mR;
@@ -161,13 +162,22 @@ stft_stereo_kernel(StftArgs a) {
                 bl = gl ? mL : bl; kl = gl ? q : kl;
                 br = gr ? mR : br; kr = gr ? q : kr;
             };
+            // Padded LDS addresses are additive over disjoint bit fields (lds_fft.h): Z[q], q = tq + TPF u, sits at
+            // pad(tq) + pad(TPF u); its mirror N - q = (N - TPF (u+1)) + (TPF - tq) at pad(TPF - tq) + a constant for
+            // every lane but tq = 0 (whose mirror N - TPF u is a constant itself) — one select instead of the
+            // subtract / mask / shift / add chain per access.
+            const float2* pq = buf + lds_pad<S>(tq);
+            const int mlow = lds_pad<S>(TPF - tq);
 #pragma unroll
             for (int u = 0; u < (N / 2) / TPF; ++u) {
                 const int q = tq + TPF * u;
-                emit(q, tq * 4, TPF * u * 4, buf[lds_pad<S>(q)], buf[lds_pad<S>((N - q) & (N - 1))]);
+                const int moff = lds_pad_c<S>(N - TPF * (u + 1));
+                const int m0 = lds_pad_c<S>((N - TPF * u) & (N - 1)) - moff;       // what tq = 0 needs in place of mlow
+                const int ml = tq == 0 ? m0 : mlow;
+                emit(q, tq * 4, TPF * u * 4, pq[lds_pad_c<S>(TPF * u)], buf[ml + moff]);
             }
             if (tq == 0) {
-                const float2 z = buf[lds_pad<S>(N / 2)];
+                const float2 z = buf[lds_pad_c<S>(N / 2)];
                 emit(N / 2, 0, (N / 2) * 4, z, z);
             }
         };

@@ -75,6 +75,8 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
 #pragma unroll
         for (int i = 0; i < P; ++i) w[i] = mk<float>(1.f, 1.f);
     }
+#pragma unroll
+    for (int i = 0; i < P; ++i) { w[i].x *= 0.5f; w[i].y *= 0.5f; }     // the 1/2 of the Hermitian split (exact)
     TwRegs<float, LOG2M, PP> tw;
     tw.load(a.twM, tl);
     constexpr int NIT = (M / 2) / TPF;
@@ -158,20 +160,26 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
                 const bool g = !(excl && (k == 0 || k == M)) && (m > best || (m == best && k < bk));
                 best = g ? m : best; bk = g ? k : bk;
             };
+            // additive padded addresses: Z[q] at pad(tq) + pad(TPF u), its mirror at pad(TPF - tq) + a constant for
+            // every lane but tq = 0 (see rfft_generic.h)
+            const float2* pq = buf + lds_pad<S>(tq);
+            const int mlow = lds_pad<S>(TPF - tq);
 #pragma unroll
             for (int u = 0; u < NIT; ++u) {                 // pair q < M/2 -> bins q and M - q
                 const int q = tq + TPF * u;
-                const float2 zq = buf[lds_pad<S>(q)], zm = buf[lds_pad<S>((M - q) & (M - 1))];
-                const float2 e = mk<float>(0.5f * (zq.x + zm.x), 0.5f * (zq.y - zm.y));
-                const float2 d = mk<float>(0.5f * (zq.x - zm.x), 0.5f * (zq.y + zm.y));
+                const int moff = lds_pad_c<S>(M - TPF * (u + 1));
+                const int m0 = lds_pad_c<S>((M - TPF * u) & (M - 1)) - moff;
+                const float2 zq = pq[lds_pad_c<S>(TPF * u)], zm = buf[(tq == 0 ? m0 : mlow) + moff];
+                const float2 e = mk<float>(zq.x + zm.x, zq.y - zm.y);          // the 1/2 is in the window
+                const float2 d = mk<float>(zq.x - zm.x, zq.y + zm.y);
                 const float2 wo = cmul(mk<float>(d.y, -d.x), tn[u]);
                 const float2 xa = cadd(e, wo), xb = csub(e, wo);
                 consider(mag_sqrt(xa.x * xa.x + xa.y * xa.y), q, tq * 4, TPF * u * 4);
                 consider(mag_sqrt(xb.x * xb.x + xb.y * xb.y), M - q, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
             }
             if (tq == 0) {                                  // bin M/2: X = conj(Z[M/2])
-                const float2 z = buf[lds_pad<S>(M / 2)];
-                consider(mag_sqrt(z.x * z.x + z.y * z.y), M / 2, 0, (M / 2) * 4);
+                const float2 z = buf[lds_pad_c<S>(M / 2)];
+                consider(2.0f * mag_sqrt(z.x * z.x + z.y * z.y), M / 2, 0, (M / 2) * 4);
             }
         };
         if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});
