@@ -111,18 +111,19 @@ static int analyze_frames_host(const T* x, int64_t batch, int32_t n, int32_t win
     const int64_t nchunks = (batch + chunk - 1) / chunk;
     const int NSET = nchunks > 1 ? 2 : 1;
     const bool want_peak = peak_bin || peak_mag || sm;
+    const bool need_mag = sm && !fused_4096<T>(n);      // the fused kernel keeps the spectrum row in LDS
     struct Set { T* x; T* mag; sa_time_stats* ts; sa_spec_metrics* sm; int32_t* pb; T* pm; hipEvent_t up; };
     Set sets[2] = {};
     Temp tmp;
     for (int i = 0; i < NSET; ++i) {
         Set& s = sets[i];
         s.x = static_cast<T*>(tmp.dev((size_t)chunk * n * sizeof(T)));
-        s.mag = sm ? static_cast<T*>(tmp.dev((size_t)chunk * nb * sizeof(T))) : nullptr;
+        s.mag = need_mag ? static_cast<T*>(tmp.dev((size_t)chunk * nb * sizeof(T))) : nullptr;
         s.ts = ts ? static_cast<sa_time_stats*>(tmp.dev((size_t)chunk * sizeof(sa_time_stats))) : nullptr;
         s.sm = sm ? static_cast<sa_spec_metrics*>(tmp.dev((size_t)chunk * sizeof(sa_spec_metrics))) : nullptr;
         s.pb = static_cast<int32_t*>(tmp.dev((size_t)chunk * sizeof(int32_t)));
         s.pm = static_cast<T*>(tmp.dev((size_t)chunk * sizeof(T)));
-        if (!s.x || (sm && (!s.mag || !s.sm)) || (ts && !s.ts) || !s.pb || !s.pm) return SA_ENOMEM;
+        if (!s.x || (need_mag && !s.mag) || (sm && !s.sm) || (ts && !s.ts) || !s.pb || !s.pm) return SA_ENOMEM;
     }
     auto run_chunk = [&](const Set& s, int64_t cnt) -> int {
         return analyze_frames_dev<T>(s.x, cnt, n, window, win_param, fs, side_hz, s.mag, s.ts, s.sm,
