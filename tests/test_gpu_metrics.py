@@ -257,13 +257,15 @@ def test_analyze_frames_one_call(dtype, n, batch):
     assert one[2] == pb[3] and one[1].fund_bin == sm[3].fund_bin and one[0].zc_count == ts[3].zc_count
 
 
-def test_fused_4096_kernel_vs_chain_and_oracle():
+@pytest.mark.parametrize("win", ["WIN_HANN", "WIN_NONE", "WIN_GAUSSIAN"])
+def test_fused_4096_kernel_vs_chain_and_oracle(win):
     """4096-point fp32 frames take the fused kernel (statistics from the load registers, metrics from the spectrum
     row in LDS).  Against the three-kernel chain on the same device buffers: spectral metrics and peaks bit-identical
     (same routine, same fp32 spectrum), time statistics equal in every integer / selected value and to 1e-12 in the
     fp64 sums (different summation order); and both against the oracle.  Edge frames: constant, all-zero, impulse,
     alternating sign, a frame whose extrema repeat."""
     lib = _lib.load()
+    WIN = getattr(_lib, win)
     n, fs = 4096, 100e3
     rng = np.random.default_rng(4096)
     t = np.arange(n) / fs
@@ -286,10 +288,10 @@ def test_fused_4096_kernel_vs_chain_and_oracle():
         dpb, dpm = _lib.DeviceBuffer(batch * 4), _lib.DeviceBuffer(batch * 4)
         bufs.extend([dts, dsm, dpb, dpm])
         if fused:
-            _lib.check(lib.sa_analyze_frames_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, fs, 10.0, dm.ptr,
+            _lib.check(lib.sa_analyze_frames_f32_dev(dx.ptr, batch, n, WIN, 0.0, fs, 10.0, dm.ptr,
                                                      dts.ptr if ts_on else None, dsm.ptr if sm_on else None, dpb.ptr, dpm.ptr, None))
         else:                                                          # the chain, entry point by entry point
-            _lib.check(lib.sa_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, _lib.F_WRITE_MAG, dm.ptr, dpb.ptr, dpm.ptr, None))
+            _lib.check(lib.sa_rfft_peak_f32_dev(dx.ptr, batch, n, WIN, 0.0, _lib.F_WRITE_MAG, dm.ptr, dpb.ptr, dpm.ptr, None))
             _lib.check(lib.sa_time_stats_f32_dev(dx.ptr, batch, n, n, dts.ptr, None))
             _lib.check(lib.sa_spectral_metrics_f32_dev(dm.ptr, batch, n, fs / n, 10.0, dsm.ptr, None))
         _lib.check(lib.sa_sync())
