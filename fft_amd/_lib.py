@@ -13,9 +13,9 @@ LIB_PATH = os.path.join(_HERE, "libspecengine.so")
 
 SA_OK, SA_EINVAL, SA_ENODEV, SA_EHIP, SA_ENOMEM, SA_EUNSUP = 0, -1, -2, -3, -4, -5
 
-WIN_NONE, WIN_HANN, WIN_HAMMING, WIN_BLACKMAN, WIN_GAUSSIAN = 0, 1, 2, 3, 4
+WIN_NONE, WIN_HANN, WIN_HAMMING, WIN_BLACKMAN, WIN_GAUSSIAN, WIN_NUTTALL = 0, 1, 2, 3, 4, 5
 WINDOW_IDS = {None: 0, "none": 0, "rect": 0, "boxcar": 0, "hann": 1, "hanning": 1, "hamming": 2,
-              "blackman": 3, "gaussian": 4, "gauss": 4}
+              "blackman": 3, "gaussian": 4, "gauss": 4, "nuttall": 5}
 F_WRITE_MAG, F_DB, F_EXCLUDE_DC_NYQ = 1, 2, 4
 
 _lib = None

@@ -230,7 +230,7 @@ extern "C" int sa_fft_mag_f64(const double* x, int64_t batch, int64_t n, int32_t
     if (!x || !peak_bin || !peak_mag) { set_error("sa_fft_mag_f64: x, peak_bin, peak_mag must be non-NULL"); return SA_EINVAL; }
     if ((flags & SA_F_WRITE_MAG) && !mag) { set_error("sa_fft_mag_f64: SA_F_WRITE_MAG set but mag is NULL"); return SA_EINVAL; }
     if (flags & ~7) { set_error("sa_fft_mag_f64: unknown flag bits"); return SA_EINVAL; }
-    if (window < SA_WIN_NONE || window > SA_WIN_GAUSSIAN) { set_error("unknown window id %d", window); return SA_EINVAL; }
+    if (window < SA_WIN_NONE || window > SA_WIN_LAST) { set_error("unknown window id %d", window); return SA_EINVAL; }
     hipStream_t st = thread_stream();
     const int64_t nb = n / 2 + 1;
     int64_t Mest = 1;

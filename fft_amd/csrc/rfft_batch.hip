@@ -131,7 +131,7 @@ template <typename T>
 static int check_args(const T* x, int64_t batch, int32_t n, int32_t window, int32_t flags, T* mag,
                       int32_t* peak_bin, T* peak_mag, int* log2n) {
     if (batch < 0) { set_error("batch must be >= 0 (got %lld)", (long long)batch); return SA_EINVAL; }
-    if (window < SA_WIN_NONE || window > SA_WIN_GAUSSIAN) { set_error("unknown window id %d", window); return SA_EINVAL; }
+    if (window < SA_WIN_NONE || window > SA_WIN_LAST) { set_error("unknown window id %d", window); return SA_EINVAL; }
     *log2n = ilog2_exact(n);
     if (*log2n < 0) { set_error("n=%d is not a power of two; use sa_fft_mag_f64 for arbitrary n", n); return SA_EUNSUP; }
     if (n < 16) { set_error("n=%d < 16 (reference rejects N < 16, main.py:512)", n); return SA_EINVAL; }

@@ -222,6 +222,9 @@ void host_window(int window, double win_param, int n, std::vector<double>& w) {
         if (window == SA_WIN_HANN) w[i] = 0.5 + 0.5 * cos(a);
         else if (window == SA_WIN_HAMMING) w[i] = 0.54 + 0.46 * cos(a);
         else if (window == SA_WIN_BLACKMAN) w[i] = 0.42 + 0.5 * cos(a) + 0.08 * cos(2.0 * a);
+        // firmware apply_window (Core/Src/main.c:92) with a = n/(N-1); here a' = pi (2n - (N-1))/(N-1) = 2 pi a - pi, so
+        // cos(2 pi a) = -cos(a'), cos(4 pi a) = cos(2a'), cos(6 pi a) = -cos(3a')
+        else if (window == SA_WIN_NUTTALL) w[i] = 0.355768 + 0.487396 * cos(a) + 0.144232 * cos(2.0 * a) + 0.012604 * cos(3.0 * a);
     }
 }
 

@@ -110,7 +110,7 @@ int sa_compute_f64(const sa_gen_params* p, int32_t window, double win_param, int
     SA_TRY(ensure_init());
     SA_TRY(check_params(p));
     if (!y_out || !mag || !peak_bin || !peak_mag) { set_error("sa_compute_f64: NULL output buffer"); return SA_EINVAL; }
-    if (window < SA_WIN_NONE || window > SA_WIN_GAUSSIAN) { set_error("unknown window id %d", window); return SA_EINVAL; }
+    if (window < SA_WIN_NONE || window > SA_WIN_LAST) { set_error("unknown window id %d", window); return SA_EINVAL; }
     if (flags & ~7) { set_error("sa_compute_f64: unknown flag bits"); return SA_EINVAL; }
     flags |= SA_F_WRITE_MAG;
     hipStream_t st = thread_stream();

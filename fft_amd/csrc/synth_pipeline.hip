@@ -281,7 +281,7 @@ int synth_analyze_dev(const sa_gen_params* dparams, int64_t batch, int32_t n_bas
         set_error("synth_analyze: n_base*upsample=%lld must be a power of two in [2048, 16384] (n_base >= 256)", (long long)n);
         return SA_EUNSUP;
     }
-    if (window < SA_WIN_NONE || window > SA_WIN_GAUSSIAN) { set_error("unknown window id %d", window); return SA_EINVAL; }
+    if (window < SA_WIN_NONE || window > SA_WIN_LAST) { set_error("unknown window id %d", window); return SA_EINVAL; }
     if (flags & ~7) { set_error("synth_analyze: unknown flag bits"); return SA_EINVAL; }
     if (!dparams || !peak_bin || !peak_mag || ((flags & SA_F_WRITE_MAG) && !mag)) { set_error("synth_analyze: NULL buffer"); return SA_EINVAL; }
     const RfftPlan* plan = get_rfft_plan(false, (int)n, window, win_param);

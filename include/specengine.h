@@ -47,6 +47,9 @@ extern "C" {
 #define SA_WIN_BLACKMAN  3   /* np.blackman(N)  = 0.42 - 0.5 cos(2 pi n/(N-1)) + 0.08 cos(4 pi n/(N-1)) */
 #define SA_WIN_GAUSSIAN  4   /* scipy.signal.windows.gaussian(N, std=win_param, sym=True);
                                 win_param <= 0 selects std = (N-1)/5                                */
+#define SA_WIN_NUTTALL   5   /* the firmware's third window (Core/Src/main.c:92): 0.355768 - 0.487396 cos(2 pi a)
+                                + 0.144232 cos(4 pi a) - 0.012604 cos(6 pi a), a = n/(N-1) (symmetric)   */
+#define SA_WIN_LAST      SA_WIN_NUTTALL
 
 /* ---- flags -------------------------------------------------------------------------------- */
 #define SA_F_WRITE_MAG       1   /* write the N/2+1 magnitudes per frame (else peak only)          */

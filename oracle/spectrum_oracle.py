@@ -229,7 +229,7 @@ def dominant_peak(f, Y, positive_only=False):
 # ---- a11: windows (numpy / scipy symmetric definitions; firmware Core/Src/main.c:83-99 agrees) ------
 def window(kind, n, param=0.0):
     kind = (kind or "none").lower() if not isinstance(kind, int) else kind
-    names = {0: "none", 1: "hann", 2: "hamming", 3: "blackman", 4: "gaussian"}
+    names = {0: "none", 1: "hann", 2: "hamming", 3: "blackman", 4: "gaussian", 5: "nuttall"}
     kind = names.get(kind, kind)
     if kind in ("none", "rect", "boxcar"):
         return np.ones(n)
@@ -243,6 +243,13 @@ def window(kind, n, param=0.0):
         std = param if param and param > 0 else (n - 1) / 5.0
         k = np.arange(n) - (n - 1) / 2.0
         return np.exp(-0.5 * (k / std) ** 2)          # scipy.signal.windows.gaussian(n, std, sym=True)
+    if kind == "nuttall":
+        # the firmware's WIN_NUTTALL (Core/Src/main.c:85-92; it evaluates in float, this is the same formula in fp64)
+        if n == 1:
+            return np.ones(1)
+        a = np.arange(n) / (n - 1.0)
+        return (0.355768 - 0.487396 * np.cos(2 * np.pi * a) + 0.144232 * np.cos(4 * np.pi * a)
+                - 0.012604 * np.cos(6 * np.pi * a))
     raise ValueError(kind)
 
 

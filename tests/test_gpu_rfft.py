@@ -24,7 +24,7 @@ def check_peaks(pb, pm, mag_ref, pb_ref, excl=False, tie_rel=1e-5):
 
 
 @pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768])
-@pytest.mark.parametrize("win", ["none", "hann", "hamming", "blackman", "gaussian"])
+@pytest.mark.parametrize("win", ["none", "hann", "hamming", "blackman", "gaussian", "nuttall"])
 def test_rfft_f32_all_sizes(n, win):
     import fft_amd
     rng = np.random.default_rng(n * 7 + len(win))
@@ -41,7 +41,7 @@ def test_rfft_f32_all_sizes(n, win):
 
 
 @pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
-@pytest.mark.parametrize("win", ["none", "hamming", "gaussian"])
+@pytest.mark.parametrize("win", ["none", "hamming", "gaussian", "nuttall"])
 def test_rfft_f64_all_sizes(n, win):
     import fft_amd
     rng = np.random.default_rng(n + 1)
