@@ -30,9 +30,24 @@ template <typename T> struct LdsPadShift { static constexpr int value = (sizeof(
 
 // elements of LDS needed per transform; congruent to 2 (mod 16) so that the columns of a
 // multi-column workgroup start on different bank groups
+// Exchange-specific padding.  The layout between pass J-1 and pass J is private to those two passes, so it can be
+// chosen for pass J's gather: thread l reads (l / M_J) M_prev + l % M_J + n M_J.  With radix 16 and 2 <= M_J <= 16 the
+// rows of 32 elements that consecutive lane groups touch are M_J / 2 rows apart, so one pad element per row shifts
+// them by half of what keeps the 32 lanes of a half-wave on distinct banks (2-way conflicts); TWO pad elements per
+// row make it conflict free, and stride-1 writes do not care.  Only for 8-byte elements (fp32); the exchange after the
+// last pass keeps the standard layout (kernel epilogues read it with lds_pad).
+template <typename T, int LR, int PP> constexpr int exch_pad_mult(int j) {       // layout read by pass j (1 <= j < NP)
+    using PL = FftPlan<LR, PP>;
+    if (sizeof(cplx<T>) != 8 || j < 1 || j >= PL::NP) return 1;
+    const int mj = PL::R / PL::H(j) / PL::radix(j);
+    return (PL::radix(j) == 16 && mj >= 2 && mj <= 16) ? 2 : 1;
+}
+template <int S, int MULT> __device__ __forceinline__ int lds_pad_m(int a) { return a + MULT * (a >> S) + (a >> (2 * S)); }
+template <int S, int MULT> constexpr int lds_pad_mc(int a) { return a + MULT * (a >> S) + (a >> (2 * S)); }
+
 template <typename T, int LR> constexpr int lds_fft_elems() {
     constexpr int S = LdsPadShift<T>::value;
-    int n = lds_pad_c<S>(1 << LR) + 1;
+    int n = (sizeof(cplx<T>) == 8 ? lds_pad_mc<S, 2>(1 << LR) : lds_pad_c<S>(1 << LR)) + 1;
     while ((n & 15) != 2) ++n;
     return n;
 }
@@ -117,14 +132,15 @@ __device__ __forceinline__ void lds_fft_pass(cplx<T>* v, cplx<T>* buf, int tl, c
         // Padded addresses are additive over disjoint bit fields of the index (see lds_pad_split below):
         // one base per pass from the lane index, everything else is a compile-time offset.
         tl &= TPF - 1;
-        const cplx<T>* rd = buf + lds_pad<S>((tl / Mj) * Mprev + (tl % Mj));
-        cplx<T>* wr = buf + lds_pad<S>(tl);
+        constexpr int MR = exch_pad_mult<T, LR, PP>(J), MW = exch_pad_mult<T, LR, PP>(J + 1);
+        const cplx<T>* rd = buf + lds_pad_m<S, MR>((tl / Mj) * Mprev + (tl % Mj));
+        cplx<T>* wr = buf + lds_pad_m<S, MW>(tl);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < P / Rj; ++u) {
             const int cu = ((TPF * u) / Mj) * Mprev + ((TPF * u) % Mj);      // index(0, u, 0): folded at unroll time
 #pragma unroll
-            for (int n = 0; n < Rj; ++n) v[u * Rj + n] = rd[lds_pad_c<S>(cu + n * Mj)];
+            for (int n = 0; n < Rj; ++n) v[u * Rj + n] = rd[lds_pad_mc<S, MR>(cu + n * Mj)];
             bfly<T, Rj>(&v[u * Rj]);
             if constexpr (Mj > 1) apply_twiddle_powers<T, Rj>(&v[u * Rj], w[u]);
         }
@@ -132,7 +148,7 @@ __device__ __forceinline__ void lds_fft_pass(cplx<T>* v, cplx<T>* buf, int tl, c
 #pragma unroll
         for (int u = 0; u < P / Rj; ++u) {
 #pragma unroll
-            for (int k = 0; k < Rj; ++k) wr[lds_pad_c<S>(TPF * u + Hprev * Mj * k)] = v[u * Rj + k];
+            for (int k = 0; k < Rj; ++k) wr[lds_pad_mc<S, MW>(TPF * u + Hprev * Mj * k)] = v[u * Rj + k];
         }
         lds_fft_pass<T, LR, PP, J + 1>(v, buf, tl, tw);
     }
@@ -150,13 +166,14 @@ __device__ __forceinline__ void lds_fft_tw(cplx<T>* v, cplx<T>* buf, int tl, con
     constexpr int Mj = R / R0;
     asm volatile("" : "+v"(tl));
     tl &= TPF - 1;
-    cplx<T>* wr = buf + lds_pad<S>(tl);
+    constexpr int MW = exch_pad_mult<T, LR, PP>(1);
+    cplx<T>* wr = buf + lds_pad_m<S, MW>(tl);
 #pragma unroll
     for (int u = 0; u < P / R0; ++u) {
         bfly<T, R0>(&v[u * R0]);
         if constexpr (PL::NP > 1) apply_twiddle_powers<T, R0>(&v[u * R0], tw.template get<0, 1, Mj>(tl + TPF * u));
 #pragma unroll
-        for (int k = 0; k < R0; ++k) wr[lds_pad_c<S>(k * Mj + TPF * u)] = v[u * R0 + k];
+        for (int k = 0; k < R0; ++k) wr[lds_pad_mc<S, MW>(k * Mj + TPF * u)] = v[u * R0 + k];
     }
     lds_fft_pass<T, LR, PP, 1>(v, buf, tl, tw);
     if constexpr (FINAL_SYNC) __syncthreads();
