@@ -208,7 +208,7 @@ static int launch_strided(C2cArgs a, hipStream_t st) {
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t ngroups = a.batch * a.A * (a.S / B);
-    const int64_t cap = (int64_t)num_cus() * 16;
+    const int64_t cap = grid_cap(16, "C2C");
     hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR, C2C_PP>::TPF * B), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
@@ -220,7 +220,7 @@ static int launch_final(C2cArgs a, hipStream_t st) {
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t ngroups = a.batch * (a.A / B);
-    const int64_t cap = (int64_t)num_cus() * 16;
+    const int64_t cap = grid_cap(16, "C2C");
     hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups < cap ? ngroups : cap)), dim3(FftPlan<LR, PP>::TPF * B), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;

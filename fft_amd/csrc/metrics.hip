@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(MT) time_stats_regs_kernel(const float* __rest
 // ---- launchers ------------------------------------------------------------------------------------------------
 constexpr int64_t WAVE_ROW_MAX = 16384;      // frames up to this length: one wavefront per frame
 static unsigned grid_for(int64_t batch) {
-    const int64_t cap = (int64_t)num_cus() * 8;
+    const int64_t cap = grid_cap(128, "METRICS");
     return (unsigned)(batch < cap ? (batch < 1 ? 1 : batch) : cap);
 }
 

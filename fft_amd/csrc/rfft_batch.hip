@@ -26,7 +26,9 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t need = (a.batch + FPW - 1) / FPW;
-    const int64_t cap = (int64_t)num_cus() * 8;
+    // more, shorter-lived workgroups than residency needs: fresh workgroups keep the waves out of step (see
+    // launch_r4k_v); measured on 4096-point frames 174 -> 187 M spectra/s going from 8 to 32 per CU
+    const int64_t cap = grid_cap(32, "GENERIC");
     const int grid = (int)(need < cap ? need : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, a);
     SA_HIP(hipGetLastError());
@@ -40,7 +42,15 @@ static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st, const R4kFuse&
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t need = (a.batch + WAVES - 1) / WAVES;
-    const int64_t cap = num_cus();                    // persistent: one workgroup per CU
+    // Grid size = frames per wave.  One persistent workgroup per CU (every wave loops over ~256 frames) is what the
+    // kernel was designed around, but measured it is the slowest choice whenever spectra are written: the waves of
+    // long-lived workgroups fall into step, and HBM sees read bursts and write bursts instead of a mix (mode A at
+    // 2^20 frames: persistent 5.57 ms, 4 frames per wave 5.19 ms, 1.9 frames per wave 4.80 - 4.87 ms, 1 frame per
+    // wave 5.21 ms — there the per-workgroup set-up shows).  The peak-only mode is VALU bound and stays persistent;
+    // the fused read-out modes sit in between.  SA_R4K_FPW10 (tuning aid): frames per wave x 10, 0 = persistent.
+    static const int fpw_env = getenv("SA_R4K_FPW10") ? atoi(getenv("SA_R4K_FPW10")) : -1;
+    const int fpw10 = fpw_env >= 0 ? fpw_env : (FUSE != 0 ? 30 : (MODE != 0 ? 19 : 0));
+    const int64_t cap = fpw10 > 0 ? (a.batch * 10 + (int64_t)WAVES * fpw10 - 1) / ((int64_t)WAVES * fpw10) : (int64_t)num_cus();
     const int grid = (int)(need < cap ? need : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, a.x, a.batch, a.frame_stride, a.win, a.twM, a.twN,
                        (a.flags & SA_F_EXCLUDE_DC_NYQ) ? 1 : 0, a.mag, a.peak_bin, a.peak_mag, a.db_floor, fz);

@@ -77,6 +77,9 @@ class Temp {
     std::vector<void*> dextra_, hextra_;
 };
 int thread_state_count();
+// workgroups a grid-stride kernel is capped at: per_cu x CUs x an optional tuning factor from the environment
+// (SA_GRIDX_<family> = percent, e.g. 400 = four times as many workgroups)
+int64_t grid_cap(int per_cu, const char* family);
 int rfft4096_metrics_dev(const float* x, int64_t batch, int32_t window, double win_param, int32_t flags, float* mag,
                          int32_t* peak_bin, float* peak_mag, sa_time_stats* ts, sa_spec_metrics* sm, double freq_step,
                          double side_hz, hipStream_t st);       // rfft_batch.hip: fused 4096-point fp32 kernel

@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -26,6 +27,15 @@ void set_error(const char* fmt, ...) {
 }
 
 int num_cus() { return g_ncus; }
+
+int64_t grid_cap(int per_cu, const char* family) {
+    char name[64];
+    snprintf(name, sizeof(name), "SA_GRIDX_%s", family);
+    const char* e = getenv(name);
+    const int64_t pct = e ? atoll(e) : 100;
+    const int64_t cap = (int64_t)g_ncus * per_cu * (pct > 0 ? pct : 100) / 100;
+    return cap > 0 ? cap : 1;
+}
 
 int ensure_init() {
     if (g_inited.load(std::memory_order_acquire)) return SA_OK;

@@ -242,7 +242,7 @@ static int launch_stereo_pp(const StftArgs& a, hipStream_t st) {
     auto kern = stft_stereo_kernel<LR, PP>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
-    const int64_t cap = (int64_t)num_cus() * 8, need = (a.nframes + FPW - 1) / FPW;
+    const int64_t cap = grid_cap(64, "STFT"), need = (a.nframes + FPW - 1) / FPW;
     hipLaunchKernelGGL(kern, dim3((unsigned)(need < cap ? need : cap)), dim3(FftPlan<LR, PP>::TPF * FPW), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;

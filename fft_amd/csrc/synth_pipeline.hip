@@ -254,7 +254,7 @@ static int launch_pipe_pp(const PipeArgs& a, hipStream_t st) {
     auto kern = synth_pipeline_kernel<LOG2M, U, PP>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
-    const int64_t cap = (int64_t)num_cus() * 4;
+    const int64_t cap = grid_cap(4, "PIPE");
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(FftPlan<LOG2M, PP>::TPF), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
