@@ -212,25 +212,34 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
     float4* slab4 = reinterpret_cast<float4*>(slab);
     float2* slab2 = reinterpret_cast<float2*>(slab);
 
-    for (int i = threadIdx.x; i < 1024; i += WAVES * 64) {
-        float4 w = win ? reinterpret_cast<const float4*>(win)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
-        w.x *= 0.5f; w.y *= 0.5f; w.z *= 0.5f; w.w *= 0.5f;
-        wtab4[i] = w;
-    }
-    __syncthreads();
-
-    // ---- per-lane twiddle bases live in a 3 KiB LDS table (they depend on the lane only), so they
-    //      occupy no registers across the frame loop: [0] w_2048^{2t} [1] w_2048^{2t+1} [2] w_128^{t&7}
-    //      [3] wA [4] wB [5] wC (Hermitian-pass bases, see below).
+    // Workgroup tables, built in ONE phase (all global loads in flight together, one barrier): with short-lived
+    // workgroups (a couple of frames per wave, see launch_r4k_v) the set-up is a visible share of a workgroup's life.
+    //  * wtab4: 0.5 * window, 1024 float4
+    //  * ctab: per-lane twiddle bases in a 3 KiB table (they depend on the lane only), so they occupy no registers
+    //    across the frame loop: [0] w_2048^{2t} [1] w_2048^{2t+1} [2] w_128^{t&7} [3] wA [4] wB [5] wC
+    //    (Hermitian-pass bases, see below).
     float2* ctab = reinterpret_cast<float2*>(smem_raw + 4096 * 4 + WAVES * R4K_SLAB_BYTES);
-    if (threadIdx.x < 64) {
-        const int t = threadIdx.x;
-        ctab[0 * 64 + t] = twM[2 * t];
-        ctab[1 * 64 + t] = twM[2 * t + 1];
-        ctab[2 * 64 + t] = twM[16 * (t & 7)];
-        ctab[3 * 64 + t] = twN[t == 0 ? 128 : t];
-        ctab[4 * 64 + t] = t == 0 ? cconj(twN[768]) : twN[t];            // lane 0: w_4096^{-768}
-        ctab[5 * 64 + t] = twN[64 + t];
+    {
+        static_assert(WAVES * 64 <= 1024, "one window quad per thread");
+        float2 c[6];
+        if (threadIdx.x < 64) {
+            const int t = threadIdx.x;
+            c[0] = twM[2 * t];
+            c[1] = twM[2 * t + 1];
+            c[2] = twM[16 * (t & 7)];
+            c[3] = twN[t == 0 ? 128 : t];
+            c[4] = t == 0 ? cconj(twN[768]) : twN[t];                    // lane 0: w_4096^{-768}
+            c[5] = twN[64 + t];
+        }
+        for (int i = threadIdx.x; i < 1024; i += WAVES * 64) {
+            float4 w = win ? reinterpret_cast<const float4*>(win)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+            w.x *= 0.5f; w.y *= 0.5f; w.z *= 0.5f; w.w *= 0.5f;
+            wtab4[i] = w;
+        }
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ctab[k * 64 + threadIdx.x] = c[k];
+        }
     }
     __syncthreads();
 
