@@ -49,7 +49,7 @@ static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st, const R4kFuse&
     // wave 5.21 ms — there the per-workgroup set-up shows).  The peak-only mode is VALU bound and stays persistent;
     // the fused read-out modes sit in between.  SA_R4K_FPW10 (tuning aid): frames per wave x 10, 0 = persistent.
     static const int fpw_env = getenv("SA_R4K_FPW10") ? atoi(getenv("SA_R4K_FPW10")) : -1;
-    const int fpw10 = fpw_env >= 0 ? fpw_env : (FUSE != 0 ? 30 : (MODE != 0 ? 19 : 0));
+    const int fpw10 = fpw_env >= 0 ? fpw_env : (FUSE != 0 ? 60 : (MODE != 0 ? 19 : 0));
     const int64_t cap = fpw10 > 0 ? (a.batch * 10 + (int64_t)WAVES * fpw10 - 1) / ((int64_t)WAVES * fpw10) : (int64_t)num_cus();
     const int grid = (int)(need < cap ? need : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, a.x, a.batch, a.frame_stride, a.win, a.twM, a.twN,
