@@ -50,7 +50,8 @@ static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st, const R4kFuse&
     // the fused read-out modes sit in between.  SA_R4K_FPW10 (tuning aid): frames per wave x 10, 0 = persistent.
     static const int fpw_env = getenv("SA_R4K_FPW10") ? atoi(getenv("SA_R4K_FPW10")) : -1;
     const int fpw10 = fpw_env >= 0 ? fpw_env : (FUSE != 0 ? 60 : (MODE != 0 ? 19 : 0));
-    const int64_t cap = fpw10 > 0 ? (a.batch * 10 + (int64_t)WAVES * fpw10 - 1) / ((int64_t)WAVES * fpw10) : (int64_t)num_cus();
+    int64_t cap = fpw10 > 0 ? (a.batch * 10 + (int64_t)WAVES * fpw10 - 1) / ((int64_t)WAVES * fpw10) : (int64_t)num_cus();
+    if (cap < num_cus()) cap = num_cus();             // small batches: every CU still gets a workgroup
     const int grid = (int)(need < cap ? need : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, a.x, a.batch, a.frame_stride, a.win, a.twM, a.twN,
                        (a.flags & SA_F_EXCLUDE_DC_NYQ) ? 1 : 0, a.mag, a.peak_bin, a.peak_mag, a.db_floor, fz);
