@@ -36,13 +36,15 @@ struct TrigF64 {
     static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
 };
 struct TrigF32 {
-    static __device__ __forceinline__ float reduced(double x) {
-        double t = x * 0.15915494309189535;          // turns
+    // the hardware sine / cosine take their argument in TURNS: exactly what the fp64 reduction produces, and one
+    // instruction instead of libm's ~35 (abs. error ~1e-6 on values that are rounded to float anyway)
+    static __device__ __forceinline__ float turns(double x) {
+        double t = x * 0.15915494309189535;
         t -= rint(t);                                // [-0.5, 0.5]
-        return (float)(t * 6.283185307179586);
+        return (float)t;
     }
-    static __device__ __forceinline__ double sin(double x) { return (double)sinf(reduced(x)); }
-    static __device__ __forceinline__ double cos(double x) { return (double)cosf(reduced(x)); }
+    static __device__ __forceinline__ double sin(double x) { return (double)__builtin_amdgcn_sinf(turns(x)); }
+    static __device__ __forceinline__ double cos(double x) { return (double)__builtin_amdgcn_cosf(turns(x)); }
 };
 
 template <typename TR = TrigF64>
