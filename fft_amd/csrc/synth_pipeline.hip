@@ -58,6 +58,8 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
     constexpr int NW = (TPF + 63) / 64;
     float* red_m = (U > 1) ? sb + NB : sb;              // no derivative array without upsampling
     int* red_k = reinterpret_cast<int*>(red_m + NW);
+    // per-interval cubic coefficients (y0, s0, slope - s0 - tt, tt): one 16-byte read per evaluated sample
+    float4* cf = reinterpret_cast<float4*>(smem_raw + (((size_t)(reinterpret_cast<char*>(red_k + NW) - smem_raw) + 15) & ~(size_t)15));
     const int tl = threadIdx.x;
     const bool excl = a.flags & SA_F_EXCLUDE_DC_NYQ;
     const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
@@ -112,29 +114,39 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
                 sb[i] = s;
             }
             __syncthreads();
-        }
-        // ---- 3. upsample + window straight into the registers of FFT pass 0 ---------------------------
-        auto sample = [&](unsigned j) -> float {          // j-th point of np.linspace(t0, t_last, N)
-            if constexpr (U == 1) {
-                return yb[j];
-            } else {
-                const unsigned num = j * (unsigned)(NB - 1);           // < 2^25
-                unsigned i = num / (unsigned)(N - 1);
-                if (i > NB - 2) i = NB - 2;
-                const float u = (float)(num - i * (unsigned)(N - 1)) * (1.0f / (float)(N - 1));
+            for (int i = tq; i < NB - 1; i += TPF) {          // scipy PPoly coefficients of interval i, dx = 1
                 const float y0 = yb[i], y1 = yb[i + 1], s0 = sb[i], s1 = sb[i + 1];
                 const float slope = y1 - y0, tt = s0 + s1 - 2.f * slope;
-                return ((tt * u + (slope - s0 - tt)) * u + s0) * u + y0;   // scipy PPoly coefficients, dx = 1
+                cf[i] = make_float4(y0, s0, slope - s0 - tt, tt);
+            }
+            __syncthreads();
+        }
+        // ---- 3. upsample + window straight into the registers of FFT pass 0 ---------------------------
+        // samples 2c and 2c+1 of np.linspace(t0, t_last, N): position j (NB-1)/(N-1) = i + r/(N-1); the second sample's
+        // (i, r) follow from the first by one add and a wrap, so the pair shares the division
+        auto sample_pair = [&](unsigned c) -> float2 {
+            if constexpr (U == 1) {
+                return mk<float>(yb[2 * c], yb[2 * c + 1]);
+            } else {
+                constexpr float INV = 1.0f / (float)(N - 1);
+                const unsigned num = 2 * c * (unsigned)(NB - 1);           // < 2^25
+                unsigned i0 = num / (unsigned)(N - 1);
+                unsigned r0 = num - i0 * (unsigned)(N - 1);
+                unsigned r1 = r0 + (unsigned)(NB - 1);
+                const bool wrap = r1 >= (unsigned)(N - 1);
+                unsigned i1 = i0 + (wrap ? 1u : 0u);
+                r1 -= wrap ? (unsigned)(N - 1) : 0u;
+                if (i1 > NB - 2) { i1 = NB - 2; r1 += (unsigned)(N - 1); }  // the very last sample: u = 1 on the last interval
+                const float4 c0 = cf[i0], c1 = cf[i1];
+                const float u0 = (float)r0 * INV, u1 = (float)r1 * INV;
+                return mk<float>(((c0.w * u0 + c0.z) * u0 + c0.y) * u0 + c0.x, ((c1.w * u1 + c1.z) * u1 + c1.y) * u1 + c1.x);
             }
         };
         float2 v[P];
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) {
-                const unsigned c = n1 * (M / R0) + tq + TPF * u;
-                v[u * R0 + n1] = mk<float>(sample(2 * c), sample(2 * c + 1));
-            }
+            for (int n1 = 0; n1 < R0; ++n1) v[u * R0 + n1] = sample_pair(n1 * (M / R0) + tq + TPF * u);
         if (a.y_out) {
             float2* yo = reinterpret_cast<float2*>(a.y_out + f * N);
 #pragma unroll
@@ -250,7 +262,7 @@ template <int LOG2M, int U, int PP>
 static int launch_pipe_pp(const PipeArgs& a, hipStream_t st) {
     constexpr int NBASE = (2 << LOG2M) / U;
     constexpr int NW = (FftPlan<LOG2M, PP>::TPF + 63) / 64;
-    constexpr int lds = lds_fft_elems<float, LOG2M>() * 8 + (U > 1 ? 2 : 1) * NBASE * 4 + NW * 8 + 16;
+    constexpr int lds = lds_fft_elems<float, LOG2M>() * 8 + (U > 1 ? 2 : 1) * NBASE * 4 + NW * 8 + 32 + (U > 1 ? NBASE * 16 : 0);
     auto kern = synth_pipeline_kernel<LOG2M, U, PP>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
