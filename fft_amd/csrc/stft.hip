@@ -350,17 +350,17 @@ int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channel
     if (seg < 1) seg = 1;
     if (seg > nframes) seg = nframes;
     const int64_t seg_samples = (seg - 1) * hop + nfft;
-    int16_t* dpcm = nullptr;
-    float *dmag = nullptr, *dpm = nullptr, *dscr = nullptr;
-    int32_t* dpb = nullptr;
     const bool wmag = flags & SA_F_WRITE_MAG;
-    hipError_t e = hipMalloc(&dpcm, (size_t)seg_samples * channels * 2);
-    if (e == hipSuccess && wmag) e = hipMalloc(&dmag, (size_t)seg * nb * channels * 4);
-    if (e == hipSuccess) e = hipMalloc(&dpm, (size_t)seg * channels * 4);
-    if (e == hipSuccess) e = hipMalloc(&dpb, (size_t)seg * channels * 4);
-    if (e == hipSuccess && !(channels == 2 && nfft <= 8192)) e = hipMalloc(&dscr, (size_t)seg_samples * 4);
+    // staging from the thread's arena (small calls reuse its cached block; large ones fall back to one allocation each)
+    Temp tmp;
+    int16_t* dpcm = static_cast<int16_t*>(tmp.dev((size_t)seg_samples * channels * 2));
+    float* dmag = wmag ? static_cast<float*>(tmp.dev((size_t)seg * nb * channels * 4)) : nullptr;
+    float* dpm = static_cast<float*>(tmp.dev((size_t)seg * channels * 4));
+    int32_t* dpb = static_cast<int32_t*>(tmp.dev((size_t)seg * channels * 4));
+    float* dscr = !(channels == 2 && nfft <= 8192) ? static_cast<float*>(tmp.dev((size_t)seg_samples * 4)) : nullptr;
     int rc = SA_OK;
-    if (e != hipSuccess) { set_error("stft: hipMalloc failed: %s", hipGetErrorString(e)); rc = SA_ENOMEM; }
+    hipError_t e = hipSuccess;
+    if (!dpcm || (wmag && !dmag) || !dpm || !dpb || (!(channels == 2 && nfft <= 8192) && !dscr)) rc = SA_ENOMEM;
     for (int64_t f0 = 0; rc == SA_OK && f0 < nframes; f0 += seg) {
         const int64_t nf = nframes - f0 < seg ? nframes - f0 : seg;
         const int64_t ns = (nf - 1) * hop + nfft;
@@ -376,12 +376,7 @@ int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channel
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("stft: D2H failed: %s", hipGetErrorString(e)); rc = SA_EHIP; }
     }
-    if (dpcm) hipFree(dpcm);
-    if (dmag) hipFree(dmag);
-    if (dpm) hipFree(dpm);
-    if (dpb) hipFree(dpb);
-    if (dscr) hipFree(dscr);
-    return rc;
+    return rc;            // every segment ended with a stream synchronise: the arena blocks are idle
 }
 
 }  // extern "C"
