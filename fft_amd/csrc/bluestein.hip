@@ -140,15 +140,19 @@ static int get_blu_plan(int64_t n, hipStream_t st, BluPlan* p) {
     if (it != cache.end()) { p->fb = it->second; return SA_OK; }
     std::vector<double> hb((size_t)M * 2);
     fill_filter(hb.data(), &c);
-    Cd *db = nullptr, *dfb = nullptr, *dw = nullptr;
-    SA_HIP(hipMalloc(&db, (size_t)M * 16));
-    SA_HIP(hipMalloc(&dfb, (size_t)M * 16));
-    if (M > 4096) SA_HIP(hipMalloc(&dw, (size_t)M * 16));
-    SA_HIP(hipMemcpy(db, hb.data(), (size_t)M * 16, hipMemcpyHostToDevice));
-    int rc = c2c_f64_dev(reinterpret_cast<double*>(db), reinterpret_cast<double*>(dfb), reinterpret_cast<double*>(dw), M, 1, 0, st);
-    if (rc == SA_OK) SA_HIP(hipStreamSynchronize(st));
-    hipFree(db);
-    if (dw) hipFree(dw);
+    Cd* dfb = nullptr;
+    SA_HIP(hipMalloc(&dfb, (size_t)M * 16));        // the cached table itself: lives until process exit
+    int rc = SA_OK;
+    {
+        Temp tmp;
+        Cd* db = static_cast<Cd*>(tmp.dev((size_t)M * 16));
+        Cd* dw = M > 4096 ? static_cast<Cd*>(tmp.dev((size_t)M * 16)) : nullptr;
+        if (!db || (M > 4096 && !dw)) rc = SA_ENOMEM;
+        if (rc == SA_OK && hipMemcpyAsync(db, hb.data(), (size_t)M * 16, hipMemcpyHostToDevice, st) != hipSuccess) rc = SA_EHIP;
+        if (rc == SA_OK) rc = c2c_f64_dev(reinterpret_cast<double*>(db), reinterpret_cast<double*>(dfb), reinterpret_cast<double*>(dw), M, 1, 0, st);
+        if (rc == SA_OK && hipStreamSynchronize(st) != hipSuccess) rc = SA_EHIP;
+        if (rc != SA_OK) (void)hipStreamSynchronize(st);   // hb / the arena must not be released under a copy in flight
+    }
     if (rc != SA_OK) { hipFree(dfb); return rc; }
     cache[{dev, n}] = dfb;       // lives until process exit
     p->fb = dfb;

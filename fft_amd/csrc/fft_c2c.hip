@@ -391,12 +391,12 @@ int sa_fft_c2c_f64(const double* in_ri, double* out_ri, int64_t n, int64_t batch
     if (batch <= 0 || n <= 0) { if (batch == 0) return SA_OK; sa::set_error("sa_fft_c2c_f64: bad n/batch"); return SA_EINVAL; }
     hipStream_t st = sa::thread_stream();
     const size_t bytes = (size_t)n * batch * 16;
-    double *din = nullptr, *dout = nullptr, *dwork = nullptr;
-    int rc = SA_OK;
-    hipError_t e = hipMalloc(&din, bytes);
-    if (e == hipSuccess) e = hipMalloc(&dout, bytes);
-    if (e == hipSuccess && n > 4096) e = hipMalloc(&dwork, bytes);
-    if (e != hipSuccess) { sa::set_error("sa_fft_c2c_f64: hipMalloc failed: %s", hipGetErrorString(e)); rc = SA_ENOMEM; }
+    sa::Temp tmp;                                   // per-thread arena; falls back to hipMalloc beyond its cache limit
+    double* din = static_cast<double*>(tmp.dev(bytes));
+    double* dout = din ? static_cast<double*>(tmp.dev(bytes)) : nullptr;
+    double* dwork = (dout && n > 4096) ? static_cast<double*>(tmp.dev(bytes)) : nullptr;
+    int rc = (!din || !dout || (n > 4096 && !dwork)) ? SA_ENOMEM : SA_OK;
+    hipError_t e = hipSuccess;
     if (rc == SA_OK) {
         e = hipMemcpyAsync(din, in_ri, bytes, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { sa::set_error("H2D copy failed: %s", hipGetErrorString(e)); rc = SA_EHIP; }
@@ -407,9 +407,7 @@ int sa_fft_c2c_f64(const double* in_ri, double* out_ri, int64_t n, int64_t batch
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { sa::set_error("D2H copy failed: %s", hipGetErrorString(e)); rc = SA_EHIP; }
     }
-    if (din) hipFree(din);
-    if (dout) hipFree(dout);
-    if (dwork) hipFree(dwork);
+    if (rc != SA_OK) (void)hipStreamSynchronize(st);   // the arena goes back with nothing in flight
     return rc;
 }
 

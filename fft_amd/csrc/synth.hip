@@ -88,19 +88,17 @@ int sa_synth_f64(const sa_gen_params* p, double* t_out, double* y_out) {
     SA_TRY(check_params(p));
     if (!y_out) { set_error("sa_synth_f64: y_out is NULL"); return SA_EINVAL; }
     hipStream_t st = thread_stream();
-    double *dy = nullptr, *dt = nullptr;
-    SA_HIP(hipMalloc(&dy, (size_t)p->N * 8));
-    int rc = SA_OK;
-    if (t_out && hipMalloc(&dt, (size_t)p->N * 8) != hipSuccess) { set_error("hipMalloc failed"); rc = SA_ENOMEM; }
+    Temp tmp;
+    double* dy = static_cast<double*>(tmp.dev((size_t)p->N * 8));
+    double* dt = t_out ? static_cast<double*>(tmp.dev((size_t)p->N * 8)) : nullptr;
+    int rc = (!dy || (t_out && !dt)) ? SA_ENOMEM : SA_OK;
     if (rc == SA_OK) rc = synth_dev(*p, dy, dt, st);
     if (rc == SA_OK) {
         hipError_t e = hipMemcpyAsync(y_out, dy, (size_t)p->N * 8, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && t_out) e = hipMemcpyAsync(t_out, dt, (size_t)p->N * 8, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { set_error("sa_synth_f64: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+        if (e != hipSuccess) { set_error("sa_synth_f64: %s", hipGetErrorString(e)); rc = SA_EHIP; (void)hipStreamSynchronize(st); }
     }
-    hipFree(dy);
-    if (dt) hipFree(dt);
     return rc;
 }
 

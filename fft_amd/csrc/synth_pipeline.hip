@@ -350,17 +350,15 @@ int sa_synth_analyze(const sa_gen_params* params, int64_t batch, int32_t n_base,
     int64_t chunk = (int64_t)(1ull << 30) / (n * 4);
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
-    sa_gen_params* dp = nullptr;
-    float *dmag = nullptr, *dpm = nullptr, *dy = nullptr;
-    int32_t* dpb = nullptr;
     const bool wmag = flags & SA_F_WRITE_MAG;
-    hipError_t e = hipMalloc(&dp, (size_t)chunk * sizeof(sa_gen_params));
-    if (e == hipSuccess && wmag) e = hipMalloc(&dmag, (size_t)chunk * nb * 4);
-    if (e == hipSuccess && y_out) e = hipMalloc(&dy, (size_t)chunk * n * 4);
-    if (e == hipSuccess) e = hipMalloc(&dpm, (size_t)chunk * 4);
-    if (e == hipSuccess) e = hipMalloc(&dpb, (size_t)chunk * 4);
-    int rc = SA_OK;
-    if (e != hipSuccess) { set_error("synth_analyze: hipMalloc failed: %s", hipGetErrorString(e)); rc = SA_ENOMEM; }
+    Temp tmp;
+    sa_gen_params* dp = static_cast<sa_gen_params*>(tmp.dev((size_t)chunk * sizeof(sa_gen_params)));
+    float* dmag = wmag ? static_cast<float*>(tmp.dev((size_t)chunk * nb * 4)) : nullptr;
+    float* dy = y_out ? static_cast<float*>(tmp.dev((size_t)chunk * n * 4)) : nullptr;
+    float* dpm = static_cast<float*>(tmp.dev((size_t)chunk * 4));
+    int32_t* dpb = static_cast<int32_t*>(tmp.dev((size_t)chunk * 4));
+    int rc = (!dp || (wmag && !dmag) || (y_out && !dy) || !dpm || !dpb) ? SA_ENOMEM : SA_OK;
+    hipError_t e = hipSuccess;
     for (int64_t b0 = 0; rc == SA_OK && b0 < batch; b0 += chunk) {
         const int64_t cnt = batch - b0 < chunk ? batch - b0 : chunk;
         e = hipMemcpyAsync(dp, params + b0, (size_t)cnt * sizeof(sa_gen_params), hipMemcpyHostToDevice, st);
@@ -374,11 +372,7 @@ int sa_synth_analyze(const sa_gen_params* params, int64_t batch, int32_t n_base,
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("synth_analyze: D2H failed: %s", hipGetErrorString(e)); rc = SA_EHIP; }
     }
-    if (dp) hipFree(dp);
-    if (dmag) hipFree(dmag);
-    if (dy) hipFree(dy);
-    if (dpm) hipFree(dpm);
-    if (dpb) hipFree(dpb);
+    if (rc != SA_OK) (void)hipStreamSynchronize(st);      // nothing may still be using the arena when it is handed back
     return rc;
 }
 
