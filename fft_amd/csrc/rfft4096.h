@@ -32,7 +32,8 @@ namespace sa {
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int R4K_SLAB_BYTES = 8 * 136 * 8;         // 8704 B private exchange slab per wave
-constexpr int r4k_lds_bytes(int waves) { return 4096 * 4 + waves * R4K_SLAB_BYTES + 6 * 64 * 8; }
+constexpr int r4k_wtab_bytes(bool half) { return half ? 2048 * 4 : 4096 * 4; }
+constexpr int r4k_lds_bytes(int waves, bool half = false) { return r4k_wtab_bytes(half) + waves * R4K_SLAB_BYTES + 6 * 64 * 8; }
 
 __device__ __forceinline__ void wave_lds_fence() {
     // Orders this wave's LDS accesses for the compiler; the hardware executes one wave's DS
@@ -187,10 +188,15 @@ struct R4kFuse {
 // MODE: 0 = peak only, 1 = write |Y|, 2 = write dB
 // FUSE: bit 0 = time statistics of the frame (from the load registers), bit 1 = derived spectral metrics (from the
 //       spectrum row staged in the wave's slab; with MODE 0 the spectrum then never reaches HBM).  Not with MODE 2.
+// NT: cache policy of the frame loads (low byte) and spectrum stores (high byte) as the aux operand of the raw buffer
+//     intrinsics (bit 1 = nontemporal); both streams are touched exactly once.
+// WH: the window is mirror-symmetric (w[n] == w[4095 - n], checked on the host per plan) and only its first half is
+//     tabulated: 8 KiB instead of 16, which is what lets TWO 8-wave workgroups share a CU (2 x 79 KiB) — the set-up,
+//     load latency and drain of one then overlap the other's arithmetic.
 // WAVES: waves per (persistent) workgroup = waves per CU.  PF: issue the next frame's 16 loads before the
 // Hermitian post-pass of the current one (needs ~64 more VGPRs, so it pairs with WAVES = 12).
-template <int MODE, int WAVES, bool PF, int FUSE = 0>
-__global__ void __launch_bounds__(WAVES * 64)
+template <int MODE, int WAVES, bool PF, int FUSE = 0, int NT = 0, int VAR = 0>
+__global__ void __launch_bounds__(WAVES * 64, (PF ? 3 : 4))   // 2nd: waves per SIMD the register budget must allow
 rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_stride, const float* __restrict__ win,
                      const float2* __restrict__ twM, const float2* __restrict__ twN, int excl_dc_nyq,
                      float* __restrict__ mag, int32_t* __restrict__ peak_bin, float* __restrict__ peak_mag,
@@ -208,7 +214,9 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
     float4* wtab4 = reinterpret_cast<float4*>(smem_raw);                 // 1024 float4: 0.5 * window
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
-    char* slab = smem_raw + 4096 * 4 + wave * R4K_SLAB_BYTES;
+    constexpr bool WH = (VAR & 1) != 0;
+    constexpr int WT_BYTES = r4k_wtab_bytes(WH);
+    char* slab = smem_raw + WT_BYTES + wave * R4K_SLAB_BYTES;
     float4* slab4 = reinterpret_cast<float4*>(slab);
     float2* slab2 = reinterpret_cast<float2*>(slab);
 
@@ -218,7 +226,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
     //  * ctab: per-lane twiddle bases in a 3 KiB table (they depend on the lane only), so they occupy no registers
     //    across the frame loop: [0] w_2048^{2t} [1] w_2048^{2t+1} [2] w_128^{t&7} [3] wA [4] wB [5] wC
     //    (Hermitian-pass bases, see below).
-    float2* ctab = reinterpret_cast<float2*>(smem_raw + 4096 * 4 + WAVES * R4K_SLAB_BYTES);
+    float2* ctab = reinterpret_cast<float2*>(smem_raw + WT_BYTES + WAVES * R4K_SLAB_BYTES);
     {
         static_assert(WAVES * 64 <= 1024, "one window quad per thread");
         float2 c[6];
@@ -231,7 +239,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
             c[4] = t == 0 ? cconj(twN[768]) : twN[t];                    // lane 0: w_4096^{-768}
             c[5] = twN[64 + t];
         }
-        for (int i = threadIdx.x; i < 1024; i += WAVES * 64) {
+        for (int i = threadIdx.x; i < WT_BYTES / 16; i += WAVES * 64) {
             float4 w = win ? reinterpret_cast<const float4*>(win)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
             w.x *= 0.5f; w.y *= 0.5f; w.z *= 0.5f; w.w *= 0.5f;
             wtab4[i] = w;
@@ -256,8 +264,11 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         asm volatile("" : "+v"(lx));
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrs, lx * 16, j * 1024, 0));
+            r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrs, lx * 16, j * 1024, NT & 0xff));
     };
+    // WH instantiations are one-shot (the launcher gives every wave exactly one frame): without a frame loop there is
+    // nothing for the compiler to hoist out of it and spill.
+    constexpr bool ONESHOT = (VAR & 2) != 0;
     for (int64_t frame = first; frame < batch; frame += nwaves) {
         // Buffer descriptors rebuilt per frame from scalars: 32-bit per-lane offsets + immediates keep
         // the address VGPRs at one per access family (no 64-bit per-lane pointers).
@@ -274,14 +285,25 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         // uses them, so they are neither hoisted out of the frame loop nor kept live across stages.
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const int x1_wr = ln;                                                // float4 index, + 68 * k1'
-        const int x1_rd = (ln >> 3) * 136 + (ln & 7);                        // float2 index, + 8 * n2
+        // exchange-1 indices: derived here, or (X1_LATE) re-derived from a fresh opaque lane copy after pass 1 — the
+        // allocator sits at the 128-register limit and which placement avoids a spill differs per instantiation
+        // (a spill reload waits on the in-order vector-memory counter, i.e. on the wave's stores as well)
+        constexpr bool X1_LATE = (MODE == 1 && FUSE == 0 && VAR == 1);
+        int x1_wr = ln;                                                      // float4 index, + 68 * k1'
+        int x1_rd = (ln >> 3) * 136 + (ln & 7);                              // float2 index, + 8 * n2
         float2 va[16], vb[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const float4 w = wtab4[j * 64 + ln];
-            va[j] = mk<float>(r[j][0] * w.x, r[j][1] * w.y);
-            vb[j] = mk<float>(r[j][2] * w.z, r[j][3] * w.w);
+            if (WH && j >= 8) {
+                // sample 256 j + 4 lane + e mirrors to 256 (15 - j) + 4 (63 - lane) + (3 - e)
+                const float4 w = wtab4[(15 - j) * 64 + (63 - ln)];
+                va[j] = mk<float>(r[j][0] * w.w, r[j][1] * w.z);
+                vb[j] = mk<float>(r[j][2] * w.y, r[j][3] * w.x);
+            } else {
+                const float4 w = wtab4[j * 64 + ln];
+                va[j] = mk<float>(r[j][0] * w.x, r[j][1] * w.y);
+                vb[j] = mk<float>(r[j][2] * w.z, r[j][3] * w.w);
+            }
         }
         // ---- pass 1: radix-16 over n1 (stride 128), twiddle w_2048^{id k1} ----------------------
         R4K_STAMP(1);                                   // [1] load issue + wait + window multiply
@@ -295,9 +317,16 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         // ---- exchange 1 + pass 2 (two halves: k1 < 8, k1 >= 8) ----------------------------------
         float2 b0[16], b1[16];
         R4K_STAMP(2);                                   // [2] pass 1
-        exch1_pass2<0>(va, vb, b0, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
+        int l1 = ln;
+        if (X1_LATE) {
+            l1 = lane;
+            asm volatile("" : "+v"(l1));
+            x1_wr = l1;
+            x1_rd = (l1 >> 3) * 136 + (l1 & 7);
+        }
+        exch1_pass2<0>(va, vb, b0, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + l1);
         R4K_STAMP(3);                                   // [3] exchange 1a + pass 2a
-        exch1_pass2<1>(va, vb, b1, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
+        exch1_pass2<1>(va, vb, b1, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + l1);
         R4K_STAMP(4);                                   // [4] exchange 1b + pass 2b
         // ---- exchange 2 + pass 3 (two halves: k2 < 8 -> hl < 128, k2 >= 8 -> hl >= 128) ---------
         int l2 = lane;
@@ -387,10 +416,18 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         // DC / Nyquist (lane 0 only): X[0] = Re Z0 + Im Z0, X[2048] = Re Z0 - Im Z0, Z0 = 2 z0
         if (special) {
             const float v0 = fabsf(2.0f * (z0.x + z0.y)), v1 = fabsf(2.0f * (z0.x - z0.y));
-            const unsigned long long keep = key;
-            emit(v0, 0, 0);
-            emit(v1, 0, 2048);
-            if (excl_dc_nyq) key = keep;
+            // Both keys by halves: as 64-bit constants their index words (4095, 2047) were hoisted out of the frame
+            // loop as register pairs and spilled.  Bin 0 wins every tie; bin 2048 loses every tie within this lane
+            // except against itself (lane 0 emits bins 128 k, all below 2048).
+            if (!excl_dc_nyq) {
+                unsigned kh = (unsigned)(key >> 32), kl = (unsigned)key;
+                const unsigned b0 = __float_as_uint(v0), b1 = __float_as_uint(v1);
+                if (b0 >= kh) { kh = b0; kl = 4095u; }
+                if (b1 > kh) { kh = b1; kl = 4095u - 2048u; }
+                key = ((unsigned long long)kh << 32) | kl;
+            }
+            if (MODE == 2) { slabf[o] = 20.0f * __log10f(fmaxf(v0, db_floor)); slabf[2048 + o] = 20.0f * __log10f(fmaxf(v1, db_floor)); }
+            else if (MODE != 0 || (FUSE & 2)) { slabf[o] = v0; slabf[2048 + o] = v1; }
         }
         if (MODE != 0) {
             wave_lds_fence();
@@ -402,11 +439,11 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
                 const int q = l4 + 64 * j;
                 const v4u d = slabq[q];
                 if (j > 0 || l4 > 0)                                 // quad 0 holds the previous row's tail
-                    __builtin_amdgcn_raw_buffer_store_b128(d, mrs, q * 16 - o * 4, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, mrs, q * 16 - o * 4, 0, NT >> 8);
             }
             if (l4 < 5) {                                            // 4 - o head floats + o + 1 tail floats
                 const int ke = l4 < 4 - o ? l4 : 2044 + l4;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(slabf[ke + o]), mrs, ke * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(slabf[ke + o]), mrs, ke * 4, 0, NT >> 8);
             }
         }
         if (FUSE & 2) {
@@ -429,6 +466,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
             }
         }
         R4K_STAMP(8);                                   // [8] peak reduction
+        if (ONESHOT) break;
     }
 #ifdef R4K_DIAG
     if (lane == 0)

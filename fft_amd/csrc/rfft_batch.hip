@@ -35,10 +35,10 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     return SA_OK;
 }
 
-template <int MODE, int WAVES, bool PF, int FUSE = 0>
+template <int MODE, int WAVES, bool PF, int FUSE = 0, int NT = 0, int VAR = 0>
 static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st, const R4kFuse& fz = R4kFuse{}) {
-    auto kern = rfft4096_wave_kernel<MODE, WAVES, PF, FUSE>;
-    constexpr int lds = r4k_lds_bytes(WAVES);
+    auto kern = rfft4096_wave_kernel<MODE, WAVES, PF, FUSE, NT, VAR>;
+    constexpr int lds = r4k_lds_bytes(WAVES, (VAR & 1) != 0);
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t need = (a.batch + WAVES - 1) / WAVES;
@@ -49,9 +49,11 @@ static int launch_r4k_v(const RfftArgs<float>& a, hipStream_t st, const R4kFuse&
     // wave 5.21 ms — there the per-workgroup set-up shows).  The peak-only mode is VALU bound and stays persistent;
     // the fused read-out modes sit in between.  SA_R4K_FPW10 (tuning aid): frames per wave x 10, 0 = persistent.
     static const int fpw_env = getenv("SA_R4K_FPW10") ? atoi(getenv("SA_R4K_FPW10")) : -1;
-    const int fpw10 = fpw_env >= 0 ? fpw_env : (FUSE != 0 ? 60 : (MODE != 0 ? 19 : 0));
+    const int fpw10 = fpw_env >= 0 ? fpw_env : (FUSE != 0 ? 60 : (MODE != 0 ? (NT != 0 ? 10 : 19) : 0));
     int64_t cap = fpw10 > 0 ? (a.batch * 10 + (int64_t)WAVES * fpw10 - 1) / ((int64_t)WAVES * fpw10) : (int64_t)num_cus();
     if (cap < num_cus()) cap = num_cus();             // small batches: every CU still gets a workgroup
+    if (VAR & 2) cap = need;                                // one-shot instantiation: exactly one frame per wave
+    if (need > 0x7fffffff) { set_error("rfft4096: batch too large for one launch"); return SA_EUNSUP; }
     const int grid = (int)(need < cap ? need : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, a.x, a.batch, a.frame_stride, a.win, a.twM, a.twN,
                        (a.flags & SA_F_EXCLUDE_DC_NYQ) ? 1 : 0, a.mag, a.peak_bin, a.peak_mag, a.db_floor, fz);
@@ -66,9 +68,35 @@ static int r4k_variant() {
     return v;
 }
 
+// Cache policy of the frame loads and spectrum stores: both are touched exactly once, so they go out nontemporal
+// (aux bit 1 = nt on the raw buffer intrinsics; template value = (store aux << 8) | load aux).  SA_R4K_NT=0 (tuning
+// aid) selects the default-policy instantiation.  The sc0 / sc1 bits measured no different on loads and -6 % on stores.
+constexpr int R4K_NT_STREAM = 0x0202;
+static bool r4k_nt() {
+    static const bool v = getenv("SA_R4K_NT") ? atoi(getenv("SA_R4K_NT")) != 0 : true;
+    return v;
+}
+
 template <int MODE>
 static int launch_r4k(const RfftArgs<float>& a, hipStream_t st) {
     if (r4k_variant() == 1) return launch_r4k_v<MODE, 12, true>(a, st);
+    // Spectra written, symmetric window: one-shot 4-wave workgroups on the half window table (rfft4096.h, VAR = 3),
+    // three to a CU — their set-up, load latency and drain overlap each other's arithmetic.  Measured at 2^20 / 2^18
+    // frames (M spectra/s; tools/wh_ab.sh): this 227 / 215-217; one looping 16-wave workgroup per CU 223-224 / 208;
+    // 8-wave one-shot (two per CU) 217 / 224; 8-wave looping 214 / 225.  SA_R4K_WH (tuning aid) picks: 0 = 16-wave
+    // looping, full table; 1 = 8-wave looping; 5 = 4-wave looping; 6 = 4-wave one-shot (default); 7 = 8-wave one-shot.
+    static const int wh = getenv("SA_R4K_WH") ? atoi(getenv("SA_R4K_WH")) : 6;
+    if constexpr (MODE != 0) {
+        if (a.win_sym && r4k_nt()) {
+            if (wh == 6) return launch_r4k_v<MODE, 4, false, 0, R4K_NT_STREAM, 3>(a, st);
+            if constexpr (MODE == 1) {
+                if (wh == 1) return launch_r4k_v<MODE, 8, false, 0, R4K_NT_STREAM, 1>(a, st);
+                if (wh == 5) return launch_r4k_v<MODE, 4, false, 0, R4K_NT_STREAM, 1>(a, st);
+                if (wh == 7) return launch_r4k_v<MODE, 8, false, 0, R4K_NT_STREAM, 3>(a, st);
+            }
+        }
+    }
+    if (r4k_nt()) return launch_r4k_v<MODE, 16, false, 0, R4K_NT_STREAM>(a, st);
     return launch_r4k_v<MODE, 16, false>(a, st);
 }
 
@@ -168,6 +196,7 @@ int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32
     a.twN = static_cast<const cplx<T>*>(p->d_twN);
     a.flags = flags; a.mag = mag; a.peak_bin = peak_bin; a.peak_mag = peak_mag;
     a.db_floor = sizeof(T) == 8 ? (T)SA_DB_FLOOR_F64 : (T)SA_DB_FLOOR_F32;
+    a.win_sym = p->win_sym;
     return dispatch_generic<T>(log2n, a, st);
 }
 
@@ -202,13 +231,24 @@ int rfft4096_metrics_dev(const float* x, int64_t batch, int32_t window, double w
     a.twN = static_cast<const cplx<float>*>(p->d_twN);
     a.flags = flags; a.mag = mag; a.peak_bin = peak_bin; a.peak_mag = peak_mag;
     a.db_floor = (float)SA_DB_FLOOR_F32;
+    a.win_sym = p->win_sym;
     const R4kFuse fz{ts, sm, freq_step, side_hz};
     const bool wmag = (flags & SA_F_WRITE_MAG) && mag;
     const int fuse = (ts ? 1 : 0) | (sm ? 2 : 0);
     if (wmag) {
+        if (r4k_nt()) {
+            if (fuse == 1) return launch_r4k_v<1, 16, false, 1, R4K_NT_STREAM>(a, st, fz);
+            if (fuse == 2) return launch_r4k_v<1, 16, false, 2, R4K_NT_STREAM>(a, st, fz);
+            return launch_r4k_v<1, 16, false, 3, R4K_NT_STREAM>(a, st, fz);
+        }
         if (fuse == 1) return launch_r4k_v<1, 16, false, 1>(a, st, fz);
         if (fuse == 2) return launch_r4k_v<1, 16, false, 2>(a, st, fz);
         return launch_r4k_v<1, 16, false, 3>(a, st, fz);
+    }
+    if (r4k_nt()) {
+        if (fuse == 1) return launch_r4k_v<0, 16, false, 1, R4K_NT_STREAM>(a, st, fz);
+        if (fuse == 2) return launch_r4k_v<0, 16, false, 2, R4K_NT_STREAM>(a, st, fz);
+        return launch_r4k_v<0, 16, false, 3, R4K_NT_STREAM>(a, st, fz);
     }
     if (fuse == 1) return launch_r4k_v<0, 16, false, 1>(a, st, fz);
     if (fuse == 2) return launch_r4k_v<0, 16, false, 2>(a, st, fz);

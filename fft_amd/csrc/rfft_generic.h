@@ -33,6 +33,7 @@ template <typename T> struct RfftArgs {
     int32_t* peak_bin;     // [batch]
     T* peak_mag;           // [batch]
     T db_floor;
+    bool win_sym = false;  // win[i] == win[n-1-i] bit for bit (from the plan); lets a kernel tabulate half the window
 };
 
 template <typename T, int LOG2M, int P /*points per thread*/, int FPW /*frames per workgroup*/>

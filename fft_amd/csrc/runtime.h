@@ -48,6 +48,7 @@ struct RfftPlan {
     void* d_win = nullptr;   // T[n] or nullptr
     void* d_twM = nullptr;   // cplx<T>[n/2]
     void* d_twN = nullptr;   // cplx<T>[n/4+1]
+    bool win_sym = true;     // the table as uploaded satisfies w[i] == w[n-1-i] bit for bit (true without a window)
 };
 // Returns a cached plan (creates it on first use; thread safe). nullptr + error on failure.
 const RfftPlan* get_rfft_plan(bool f64, int n, int window, double win_param);

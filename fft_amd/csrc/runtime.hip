@@ -315,6 +315,8 @@ const RfftPlan* get_rfft_plan(bool f64, int n, int window, double win_param) {
     int rc = SA_OK;
     if (window != SA_WIN_NONE) {
         host_window(window, win_param, n, w);
+        for (int i = 0; i < n / 2 && p->win_sym; ++i)
+            p->win_sym = f64 ? w[i] == w[n - 1 - i] : (float)w[i] == (float)w[n - 1 - i];
         rc = f64 ? upload<double>(w, &p->d_win) : upload<float>(w, &p->d_win);
     }
     if (rc == SA_OK) rc = f64 ? upload<double>(twM, &p->d_twM) : upload<float>(twM, &p->d_twM);
