@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspecengine.so")
+LIB_PATH = os.environ.get("SA_LIBSPECENGINE") or os.path.join(_HERE, "libspecengine.so")   # override: A/B builds (tools/)
 
 SA_OK, SA_EINVAL, SA_ENODEV, SA_EHIP, SA_ENOMEM, SA_EUNSUP = 0, -1, -2, -3, -4, -5
 

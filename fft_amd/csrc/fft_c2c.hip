@@ -30,6 +30,18 @@ using Cd = double2;
 #define C2C_PP 8
 #endif
 
+// Streaming accesses of the long transforms (every pass reads and writes far more than the caches hold, each element
+// once): nontemporal, as in rfft4096.h.
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ __forceinline__ Cd ld_c(const Cd* p) {
+    if (NT) { const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p)); return Cd{v.x, v.y}; }
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ void st_c(Cd* p, Cd z) {
+    if (NT) { v2d v; v.x = z.x; v.y = z.y; __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p)); }
+    else *p = z;
+}
+
 struct C2cArgs {
     const Cd* in;
     Cd* out;
@@ -56,7 +68,7 @@ struct C2cArgs {
 //   counter.  With one 128 KiB workgroup per CU nothing else covers the latency of 1024 x 128-byte reads 16 MiB
 //   apart: timing-only variants put that pass at 9.1 ms without the transform and 12.3 ms with it, while the
 //   second pass (rows 16 KiB apart) hides the same transform completely.
-template <int LR, int B, bool FAR>
+template <int LR, int B, bool FAR, bool STREAM = false>
 __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pass(C2cArgs a) {
     using PL = FftPlan<LR, C2C_PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
@@ -80,7 +92,7 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) d[u * R0 + n1] = a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S];
+            for (int n1 = 0; n1 < R0; ++n1) d[u * R0 + n1] = ld_c<STREAM>(&a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S]);
     };
     if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x, v);
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -127,7 +139,7 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
                 bs[t] = w;
             }
             const int k = k0 + TPF * u;
-            outp[(int64_t)k * a.S] = cmul(smem[c * LDSF + lds_pad<S>(k)], w);
+            st_c<STREAM>(&outp[(int64_t)k * a.S], cmul(smem[c * LDSF + lds_pad<S>(k)], w));
         }
         if (FAR) {
 #pragma unroll
@@ -138,7 +150,7 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
 }
 
 // ---- final (contiguous rows) pass ------------------------------------------------------------------
-template <int LR, int B, int PP = C2C_PP>
+template <int LR, int B, int PP = C2C_PP, bool STREAM = false>
 __global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * B)) c2c_final_pass(C2cArgs a) {
     using PL = FftPlan<LR, PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
@@ -159,7 +171,7 @@ __global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * B)) c2c_final_pass(C2c
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) v[u * R0 + n1] = src[n1 * (R / R0) + tl + TPF * u];
+            for (int n1 = 0; n1 < R0; ++n1) v[u * R0 + n1] = ld_c<STREAM>(&src[n1 * (R / R0) + tl + TPF * u]);
     };
     if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x);
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -180,7 +192,7 @@ __global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * B)) c2c_final_pass(C2c
             z.x *= a.scale; z.y *= a.scale;
             if (a.conj_out) z.y = -z.y;
             const int64_t o = a.natural ? (r0 + c) + a.A * (int64_t)k : (r0 + c) * R + k;
-            a.out[b * a.n + o] = z;
+            st_c<STREAM>(&a.out[b * a.n + o], z);
         }
         __syncthreads();
     }
@@ -200,11 +212,11 @@ static const Cd* tw_table(int64_t n, int64_t count, int64_t stride) {
     return static_cast<const Cd*>(get_cached_table(key, (size_t)count * 16, fill_tw, &c));
 }
 
-template <int LR, int B, bool FAR = false>
+template <int LR, int B, bool FAR = false, bool NT = false>
 static int launch_strided(C2cArgs a, hipStream_t st) {
     constexpr int lds = lds_fft_elems<double, LR>() * B * 16 + (FAR ? (16 << LR) : 0);
     static_assert(lds <= 160 * 1024, "strided pass does not fit LDS");
-    auto kern = c2c_strided_pass<LR, B, FAR>;
+    auto kern = c2c_strided_pass<LR, B, FAR, NT>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t ngroups = a.batch * a.A * (a.S / B);
@@ -213,10 +225,10 @@ static int launch_strided(C2cArgs a, hipStream_t st) {
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
-template <int LR, int B, int PP = C2C_PP>
+template <int LR, int B, int PP = C2C_PP, bool NT = false>
 static int launch_final(C2cArgs a, hipStream_t st) {
     constexpr int lds = lds_fft_elems<double, LR>() * B * 16;
-    auto kern = c2c_final_pass<LR, B, PP>;
+    auto kern = c2c_final_pass<LR, B, PP, NT>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t ngroups = a.batch * (a.A / B);
@@ -226,6 +238,13 @@ static int launch_final(C2cArgs a, hipStream_t st) {
     return SA_OK;
 }
 
+// Nontemporal passes once the data set is far beyond the caches (>= SA_C2C_NT_MIB MiB per buffer, default 1024;
+// 0 = never): below that the next pass still finds part of this one's output in L2 / MALL.
+static bool c2c_stream_nt(const C2cArgs& a) {
+    static const long mib = getenv("SA_C2C_NT_MIB") ? atol(getenv("SA_C2C_NT_MIB")) : 1024;
+    return mib > 0 && a.n * a.batch * 16 >= mib * (1L << 20);
+}
+
 // FAR variant for the radix-1024 and radix-512 passes of long transforms (every workgroup then loops over several
 // column groups, which is what the early loads pay off on; measured 2^27: 3.24 -> 3.06 ms, 2^29: 14.7 -> 13.9 ms,
 // first two passes of 2^30: 13.2 + 9.1 -> 12.5 + 8.4 ms; short transforms lose a few percent to its set-up).
@@ -233,6 +252,10 @@ static int launch_final(C2cArgs a, hipStream_t st) {
 static int run_strided(int lr, const C2cArgs& a, hipStream_t st) {
     static const int far_env = getenv("SA_C2C_FAR") ? atoi(getenv("SA_C2C_FAR")) : 3;
     const int far = a.batch * a.A * (a.S / 8) >= 8 * (int64_t)num_cus() ? far_env : 0;
+    if (c2c_stream_nt(a)) {
+        if (lr == 10 && (far & 1)) return launch_strided<10, 8, true, true>(a, st);
+        if (lr == 9 && (far & 2)) return launch_strided<9, 8, true, true>(a, st);
+    }
     if (lr == 10 && (far & 1)) return launch_strided<10, 8, true>(a, st);
     if (lr == 9 && (far & 2)) return launch_strided<9, 8, true>(a, st);
     switch (lr) {
@@ -249,6 +272,10 @@ static int run_final_multi(int lr, const C2cArgs& a, hipStream_t st) {
     // 1024-point rows: 16 points per thread (512 threads, 208 VGPRs) measured 8.7 -> 7.8 ms at 2^30; 512-point rows
     // gain nothing from it.  SA_C2C_FINAL_PP16=0 (tuning aid) turns it off.
     static const int pp16 = getenv("SA_C2C_FINAL_PP16") ? atoi(getenv("SA_C2C_FINAL_PP16")) : 1;
+    if (c2c_stream_nt(a)) {
+        if (lr == 10 && (pp16 & 1)) return launch_final<10, 8, 16, true>(a, st);
+        if (lr == 9) return launch_final<9, 8, C2C_PP, true>(a, st);
+    }
     if (lr == 10 && (pp16 & 1) && a.batch * (a.A / 8) >= 8 * (int64_t)num_cus()) return launch_final<10, 8, 16>(a, st);
     switch (lr) {
         case 6: return launch_final<6, 8>(a, st);

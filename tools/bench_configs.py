@@ -179,7 +179,7 @@ if __name__ == "__main__":
     if "c4" in which:
         results.append(bench_c4()); print(json.dumps(results[-1]), flush=True)
     if "c5" in which:
-        for l in (24, 27, 30):
+        for l in [int(v) for v in os.environ.get("C5_LOG2", "24,27,30").split(",")]:
             results.append(bench_c5(l)); print(json.dumps(results[-1]), flush=True)
             torch.cuda.empty_cache()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
