@@ -8,7 +8,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 // thread = (row slot tl, column c); each thread moves PER rows of its group: rows tl + TPG*u
-template <int THREADS, int PER, int COLS = 8>
+template <int THREADS, int PER, int COLS = 8, bool NT = false>
 __global__ void __launch_bounds__(THREADS) k(const v2d* in, v2d* out, long R, long S, long ngroups) {
     constexpr int TPG = THREADS / COLS;
     const int c = threadIdx.x % COLS, tl = threadIdx.x / COLS;
@@ -17,26 +17,26 @@ __global__ void __launch_bounds__(THREADS) k(const v2d* in, v2d* out, long R, lo
         for (long r0 = 0; r0 < R; r0 += (long)TPG * PER) {
             v2d v[PER];
 #pragma unroll
-            for (int u = 0; u < PER; ++u) v[u] = in[(r0 + tl + (long)TPG * u) * S + s];
+            for (int u = 0; u < PER; ++u) v[u] = NT ? __builtin_nontemporal_load(&in[(r0 + tl + (long)TPG * u) * S + s]) : in[(r0 + tl + (long)TPG * u) * S + s];
 #pragma unroll
-            for (int u = 0; u < PER; ++u) out[(r0 + tl + (long)TPG * u) * S + s] = v[u];
+            for (int u = 0; u < PER; ++u) { if (NT) __builtin_nontemporal_store(v[u], &out[(r0 + tl + (long)TPG * u) * S + s]); else out[(r0 + tl + (long)TPG * u) * S + s] = v[u]; }
         }
     }
 }
 
-template <int THREADS, int PER, int COLS = 8>
+template <int THREADS, int PER, int COLS = 8, bool NT = false>
 int run(const v2d* din, v2d* dout, long R, long S, int wg_per_cu) {
     if (R % ((long)(THREADS / COLS) * PER) != 0) { printf("skip: R must be a multiple of rows-per-sweep\n"); return 0; }   // else rows past R are touched
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k<THREADS, PER, COLS>), dim3(256 * wg_per_cu), dim3(THREADS), 0, 0, din, dout, R, S, S / COLS);
+        hipLaunchKernelGGL((k<THREADS, PER, COLS, NT>), dim3(256 * wg_per_cu), dim3(THREADS), 0, 0, din, dout, R, S, S / COLS);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    printf("R=%ld S=%ld threads=%4d per=%2d cols=%2d wg/cu=%d : %.3f ms  %.0f GB/s (read+write)\n", R, S, THREADS, PER, COLS, wg_per_cu, best,
+    printf("R=%ld S=%ld threads=%4d per=%2d cols=%2d nt=%d wg/cu=%d : %.3f ms  %.0f GB/s (read+write)\n", R, S, THREADS, PER, COLS, (int)NT, wg_per_cu, best,
            2.0 * R * S * 16 / best / 1e6);
     return 0;
 }
@@ -59,5 +59,9 @@ int main(int argc, char** argv) {
     run<1024, 16, 16>(din, dout, R, S, 2);
     run<1024, 32, 32>(din, dout, R, S, 1);   // 512-byte segments
     run<1024, 32, 32>(din, dout, R, S, 2);
+    run<1024, 8, 8, true>(din, dout, R, S, 1);     // nontemporal, as the long passes now are
+    run<1024, 8, 8, true>(din, dout, R, S, 2);
+    run<256, 16, 8, true>(din, dout, R, S, 8);
+    run<1024, 16, 16, true>(din, dout, R, S, 1);
     return 0;
 }
