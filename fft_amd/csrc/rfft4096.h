@@ -285,12 +285,8 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         // uses them, so they are neither hoisted out of the frame loop nor kept live across stages.
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        // exchange-1 indices: derived here, or (X1_LATE) re-derived from a fresh opaque lane copy after pass 1 — the
-        // allocator sits at the 128-register limit and which placement avoids a spill differs per instantiation
-        // (a spill reload waits on the in-order vector-memory counter, i.e. on the wave's stores as well)
-        constexpr bool X1_LATE = (MODE == 1 && FUSE == 0 && VAR == 1);
-        int x1_wr = ln;                                                      // float4 index, + 68 * k1'
-        int x1_rd = (ln >> 3) * 136 + (ln & 7);                              // float2 index, + 8 * n2
+        const int x1_wr = ln;                                                // float4 index, + 68 * k1'
+        const int x1_rd = (ln >> 3) * 136 + (ln & 7);                        // float2 index, + 8 * n2
         float2 va[16], vb[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -317,16 +313,9 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         // ---- exchange 1 + pass 2 (two halves: k1 < 8, k1 >= 8) ----------------------------------
         float2 b0[16], b1[16];
         R4K_STAMP(2);                                   // [2] pass 1
-        int l1 = ln;
-        if (X1_LATE) {
-            l1 = lane;
-            asm volatile("" : "+v"(l1));
-            x1_wr = l1;
-            x1_rd = (l1 >> 3) * 136 + (l1 & 7);
-        }
-        exch1_pass2<0>(va, vb, b0, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + l1);
+        exch1_pass2<0>(va, vb, b0, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
         R4K_STAMP(3);                                   // [3] exchange 1a + pass 2a
-        exch1_pass2<1>(va, vb, b1, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + l1);
+        exch1_pass2<1>(va, vb, b1, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
         R4K_STAMP(4);                                   // [4] exchange 1b + pass 2b
         // ---- exchange 2 + pass 3 (two halves: k2 < 8 -> hl < 128, k2 >= 8 -> hl >= 128) ---------
         int l2 = lane;
