@@ -86,6 +86,7 @@ static int launch_r4k(const RfftArgs<float>& a, hipStream_t st) {
     // 223-224 / 208; 8-wave one-shot (two per CU) 217 / 224; 8-wave looping 214 / 225 (the 8-wave forms are no longer
     // instantiated).  SA_R4K_WH=0 (tuning aid) selects the looping 16-wave workgroup.
     static const int wh = getenv("SA_R4K_WH") ? atoi(getenv("SA_R4K_WH")) : 6;
+    // (peak-only mode measured 286 M/s in the one-shot form against 291 M/s looping: it stays persistent)
     if constexpr (MODE != 0) {
         if (a.win_sym && r4k_nt()) {
             if (wh == 6) return launch_r4k_v<MODE, 4, false, 0, R4K_NT_STREAM, 3>(a, st);
