@@ -74,7 +74,7 @@ static int analyze_frames_dev(const T* x, int64_t batch, int32_t n, int32_t wind
         if (!pb) { pb = static_cast<int32_t*>(tmp.dev((size_t)batch * sizeof(int32_t))); if (!pb) return SA_ENOMEM; borrowed = true; }
         if (!pm) { pm = static_cast<T*>(tmp.dev((size_t)batch * sizeof(T))); if (!pm) return SA_ENOMEM; borrowed = true; }
     }
-    if (fused_4096<T>(n) && (ts || sm) && pb) {
+    if (fused_4096<T>(n) && (ts || sm) && pb && (reinterpret_cast<uintptr_t>(x) % 16) == 0) {   // 16-byte loads per lane
         // 4096-point fp32 frames whose transform is wanted anyway: statistics and metrics are computed inside the
         // transform kernel, from the load registers and from the spectrum row in LDS — one read of the frames, no
         // spectrum traffic at all

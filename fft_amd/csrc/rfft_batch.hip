@@ -113,7 +113,10 @@ static int dispatch_generic(int log2n, const RfftArgs<T>& a, hipStream_t st);
 
 template <>
 int dispatch_generic<float>(int log2n, const RfftArgs<float>& a, hipStream_t st) {
-    if (log2n == 12 && !use_generic_only() && (a.frame_stride % 4) == 0) {
+    // the wave kernel moves 16 bytes per lane: frames and spectrum buffer must sit on 16-byte boundaries
+    const bool al16 = (a.frame_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(a.x) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(a.mag) % 16) == 0;
+    if (log2n == 12 && !use_generic_only() && al16) {
         const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
         if (!wmag) return launch_r4k<0>(a, st);
         return (a.flags & SA_F_DB) ? launch_r4k<2>(a, st) : launch_r4k<1>(a, st);
@@ -193,6 +196,7 @@ int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32
     a.flags = flags; a.mag = mag; a.peak_bin = peak_bin; a.peak_mag = peak_mag;
     a.db_floor = sizeof(T) == 8 ? (T)SA_DB_FLOOR_F64 : (T)SA_DB_FLOOR_F32;
     a.win_sym = p->win_sym;
+    a.unaligned = (a.frame_stride % 2) != 0 || (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T))) != 0;
     return dispatch_generic<T>(log2n, a, st);
 }
 
@@ -215,6 +219,7 @@ int rfft4096_metrics_dev(const float* x, int64_t batch, int32_t window, double w
     int log2n = 0;
     SA_TRY(check_args(x, batch, 4096, window, flags, mag, peak_bin, peak_mag, &log2n));
     if (flags & SA_F_DB) { set_error("fused metrics need the linear spectrum (SA_F_DB not allowed)"); return SA_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(x) % 16) || (reinterpret_cast<uintptr_t>(mag) % 16)) { set_error("fused metrics: x and mag must be 16-byte aligned"); return SA_EINVAL; }
     if (!ts && !sm) { set_error("fused metrics: ts and sm are both NULL"); return SA_EINVAL; }
     if (sm && (!(freq_step > 0) || !(freq_step < INFINITY))) { set_error("fused metrics: freq_step must be a positive finite number"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;

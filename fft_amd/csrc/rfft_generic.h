@@ -34,6 +34,7 @@ template <typename T> struct RfftArgs {
     T* peak_mag;           // [batch]
     T db_floor;
     bool win_sym = false;  // win[i] == win[n-1-i] bit for bit (from the plan); lets a kernel tabulate half the window
+    bool unaligned = false; // x + b * frame_stride is not a multiple of two elements for some b: load element-wise
 };
 
 template <typename T, int LOG2M, int P /*points per thread*/, int FPW /*frames per workgroup*/>
@@ -98,11 +99,21 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
         // ---------------- global load (+window) into the first pass' registers, FFT through LDS -----
         // All loads of the frame are issued back to back (no per-element branch: frames past the end of
         // the batch re-read frame 0 and are discarded at the stores).
+        if (a.unaligned) {                               // frames may start on an odd sample (odd STFT hop): element loads
 #pragma unroll
-        for (int u = 0; u < P / R0; ++u)
+            for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1)
-                v[u * R0 + n1] = reinterpret_cast<const C*>(xf)[n1 * (M / R0) + tq + TPF * u];
+                for (int n1 = 0; n1 < R0; ++n1) {
+                    const T* xs = xf + 2 * (n1 * (M / R0) + tq + TPF * u);
+                    v[u * R0 + n1] = mk<T>(xs[0], xs[1]);
+                }
+        } else {
+#pragma unroll
+            for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+                for (int n1 = 0; n1 < R0; ++n1)
+                    v[u * R0 + n1] = reinterpret_cast<const C*>(xf)[n1 * (M / R0) + tq + TPF * u];
+        }
         if constexpr (HOIST) {
 #pragma unroll
             for (int i = 0; i < P; ++i) { v[i].x *= w[i].x; v[i].y *= w[i].y; }

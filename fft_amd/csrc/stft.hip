@@ -304,7 +304,7 @@ int stft_pcm16_dev(const int16_t* pcm, int64_t n_samples, int32_t channels, int3
         }
     }
     // generic channel count: de-interleave + convert, then strided batched rfft
-    if (hop % 2) { set_error("stft: odd hop is only supported for stereo input with nfft <= 8192"); return SA_EUNSUP; }
+    // (an odd hop starts every other frame on an odd sample: rfft_peak_strided_dev then loads element-wise)
     if (!scratch) { set_error("stft: this channel layout needs a scratch buffer of n_samples floats"); return SA_EINVAL; }
     const int64_t nb = nfft / 2 + 1;
     for (int ch = 0; ch < channels; ++ch) {

@@ -7,6 +7,11 @@ from oracle import spectrum_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-300)
+
+
 def synth_pcm(ns, ch, seed):
     rng = np.random.default_rng(seed)
     t = np.arange(ns) / 44100.0
@@ -42,6 +47,44 @@ def test_stft_stereo(nfft, hop):
 def test_stft_other_channel_counts(ch):
     check(synth_pcm(30000, ch, ch), 4096, 1024, "hann")
     check(synth_pcm(30000, ch, ch), 2048, 512, "none")
+
+
+@pytest.mark.parametrize("ch,nfft,hop", [(1, 1024, 255), (1, 4096, 1023), (1, 64, 1), (3, 2048, 511), (2, 16384, 4097)])
+def test_stft_odd_hop_deinterleaved_paths(ch, nfft, hop):
+    """Odd hops start every other frame on an odd sample; the de-interleaved (mono / 3-channel / nfft > 8192) paths
+    then load the frames element-wise (rfft_generic.h, RfftArgs::unaligned).  4096-point frames at an odd hop also
+    keep off the 16-byte-per-lane wave kernel."""
+    check(synth_pcm(nfft * 3 + 77, ch, 5 + ch), nfft, hop, "hann")
+
+
+def test_rfft_unaligned_device_buffers():
+    """Device pointers that are only 4-byte aligned (a view one float into a buffer): 4096-point frames take the
+    generic kernel's element loads instead of the 16-byte wave kernel; results equal the aligned call bit for bit."""
+    import ctypes as C
+    import torch
+    from fft_amd import _lib
+    lib = _lib.load(); _lib.check(lib.sa_init(0))
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for n in (4096, 1024):
+        batch = 37
+        g = torch.Generator(device="cuda"); g.manual_seed(n)
+        buf = torch.empty(batch * n + 1, dtype=torch.float32, device="cuda").normal_(generator=g)
+        x_un = buf[1:].view(batch, n)                                   # 4-byte aligned only
+        x_al = x_un.clone()
+        outs = []
+        for x in (x_un, x_al):
+            mag = torch.empty((batch, n // 2 + 1), dtype=torch.float32, device="cuda")
+            pb = torch.empty(batch, dtype=torch.int32, device="cuda"); pm = torch.empty(batch, dtype=torch.float32, device="cuda")
+            _lib.check(lib.sa_rfft_peak_f32_dev(P(x), batch, n, _lib.WIN_HANN, 0.0, _lib.F_WRITE_MAG, P(mag), P(pb), P(pm),
+                                                _lib.torch_stream()))
+            torch.cuda.synchronize()
+            outs.append((mag, pb, pm))
+        mref, pbref, _ = O.rfft_mag_peak(x_al.cpu().numpy(), "hann")
+        for mag, pb, pm in outs:
+            assert rel_l2(mag.cpu().numpy(), mref).max() < 1e-5 * np.log2(n)
+            assert (pb.cpu().numpy() == pbref).all()
+        if n != 4096:                                                   # same kernel, same arithmetic
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def test_stft_edges():

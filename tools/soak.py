@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Randomised soak of the C ABI against the CPU oracle (run on the GPU box; not part of pytest).
+
+Draws (entry point, size, batch, window, flags, input kind) at random for a time budget and checks every result to
+the bars the tests use: peak bins identical to np.argmax on the oracle spectrum (a frame whose oracle top-2 gap is
+below 1e-5 relative may take either), fp32 spectra within 1e-5*log2(n) relative L2, fp64 within 1e-12 of the row
+maximum.  Every case is reproducible from the printed (seed, case number).
+usage: python tools/soak.py [seconds=120] [seed=1]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import fft_amd  # noqa: E402
+from oracle import spectrum_oracle as O  # noqa: E402
+
+WINDOWS = ["none", "hann", "hamming", "blackman", "gaussian", "nuttall"]
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-300)
+
+
+def peaks_ok(pb, mag_ref, pb_ref, excl):
+    bad = np.nonzero(np.asarray(pb) != np.asarray(pb_ref))[0]
+    if len(bad) == 0:
+        return True
+    return bool((O.top2_gap(mag_ref[bad], excl) < 1e-5).all())
+
+
+def make_frames(rng, batch, n, dtype):
+    kind = rng.integers(0, 6)
+    t = np.arange(n)
+    if kind == 0:
+        x = rng.standard_normal((batch, n))
+    elif kind == 1:                                   # tone + noise
+        f = rng.uniform(0, 0.5, (batch, 1)); a = rng.uniform(0.1, 2, (batch, 1)); ph = rng.uniform(0, 6.28, (batch, 1))
+        x = a * np.sin(2 * np.pi * f * t + ph) + 0.01 * rng.standard_normal((batch, n))
+    elif kind == 2:                                   # exact on-bin tones (ties between +/- leakage are impossible, peak exact)
+        k = rng.integers(0, n // 2 + 1, (batch, 1))
+        x = np.cos(2 * np.pi * k * t / n)
+    elif kind == 3:                                   # impulses
+        x = np.zeros((batch, n)); x[np.arange(batch), rng.integers(0, n, batch)] = rng.uniform(-3, 3, batch)
+    elif kind == 4:                                   # constant / zeros mixed
+        x = np.repeat(rng.choice([0.0, 1.0, -2.5], (batch, 1)), n, axis=1)
+    else:                                             # large dynamic range
+        x = rng.standard_normal((batch, n)) * 10.0 ** rng.uniform(-6, 6, (batch, 1))
+    return np.ascontiguousarray(x.astype(dtype)), int(kind)
+
+
+def case_rfft(rng):
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    n = 1 << int(rng.integers(4, 15))
+    batch = int(rng.integers(1, max(2, min(3000, (1 << 22) // n))))
+    win = WINDOWS[rng.integers(0, len(WINDOWS))]
+    wp = float(rng.uniform(n / 20, n / 3)) if win == "gaussian" else 0.0
+    excl = bool(rng.integers(0, 2)); db = bool(rng.integers(0, 2)) and rng.random() < 0.3
+    wmag = rng.random() < 0.8
+    x, kind = make_frames(rng, batch, n, dtype)
+    desc = dict(fn="rfft_peak", dtype=str(np.dtype(dtype)), n=n, batch=batch, win=win, wp=wp, excl=excl, db=db, wmag=wmag, kind=kind)
+    mag, pb, pm = fft_amd.rfft_peak(x, window=win, win_param=wp, write_mag=wmag, db=db, exclude_dc_nyq=excl)
+    mref, pbref, pmref = O.rfft_mag_peak(x, win, wp, db=False, exclude_dc_nyq=excl)
+    pb = np.asarray(pb); pm = np.asarray(pm, dtype=np.float64)
+    # Degenerate rows are measured against a floor instead of their own (rounding-noise) size: an impulse sitting where
+    # the window is ~0 (np.blackman's end points are -1.4e-17, the library's table has the exact 0; Gaussian tails
+    # underflow when squared in fp32) has a "spectrum" of 1e-17 * amplitude in the oracle.
+    xmax = np.abs(x).max(axis=1).astype(np.float64)
+    live = mref.max(axis=1) > 1e-2 * xmax                      # rows with a real spectrum
+    if live.any() and not peaks_ok(pb[live], mref[live], pbref[live], excl):
+        return desc, "peak bins differ beyond ties"
+    tol = 1e-5 * np.log2(n) if dtype == np.float32 else 1e-12
+    if wmag and not db:
+        if dtype == np.float32:
+            scale = np.maximum(np.linalg.norm(mref, axis=1), 1e-2 * xmax * np.sqrt(mref.shape[1]))
+            err = np.linalg.norm(mag.astype(np.float64) - mref, axis=1) / np.maximum(scale, 1e-300)
+            if err.max() > tol:
+                return desc, f"rel-L2 {err.max():.3g} > {tol:.3g}"
+        else:
+            scale = np.maximum(np.maximum(mref.max(axis=1), 1e-2 * xmax), 1e-300)[:, None]
+            if (np.abs(mag - mref) / scale).max() > tol:
+                return desc, f"fp64 error {(np.abs(mag - mref) / scale).max():.3g}"
+    if wmag and db and live.any():
+        sel = (mref > 1e-3 * np.maximum(mref.max(axis=1, keepdims=True), 1e-300)) & live[:, None]
+        if sel.any() and np.abs(mag[sel] - 20 * np.log10(mref[sel])).max() > (2e-3 if dtype == np.float32 else 1e-9):
+            return desc, "dB values differ"
+    same = (pb == pbref) & live
+    if same.any():
+        rt = 2e-4 if dtype == np.float32 else 1e-11
+        if not np.allclose(pm[same], pmref[same], rtol=rt, atol=0):
+            return desc, "peak magnitudes differ"
+    return desc, None
+
+
+def case_stft(rng):
+    ch = int(rng.integers(1, 3))
+    nfft = 1 << int(rng.integers(4, 14))
+    hop = int(rng.integers(1, nfft + 1)) if rng.random() < 0.5 else nfft // int(2 ** rng.integers(0, 4))
+    nf = int(rng.integers(1, max(2, min(400, (1 << 21) // nfft))))
+    ns = nfft + (nf - 1) * hop + int(rng.integers(0, hop))
+    win = WINDOWS[rng.integers(0, len(WINDOWS))]
+    wp = float(nfft / 6) if win == "gaussian" else 0.0
+    excl = bool(rng.integers(0, 2))
+    pcm = rng.integers(-32768, 32768, (ns, ch), dtype=np.int16)
+    if rng.random() < 0.5:
+        t = np.arange(ns)[:, None]
+        pcm = (20000 * np.sin(2 * np.pi * rng.uniform(0.001, 0.45, (1, ch)) * t) + 50 * rng.standard_normal((ns, ch))).astype(np.int16)
+    desc = dict(fn="stft_pcm16", ch=ch, nfft=nfft, hop=hop, ns=ns, win=win, excl=excl)
+    mag, pb, pm = fft_amd.stft_pcm16(pcm, nfft=nfft, hop=hop, window=win, win_param=wp, exclude_dc_nyq=excl)
+    mref, pbref, pmref = O.stft_pcm16(pcm, nfft, hop, win, wp, exclude_dc_nyq=excl)
+    if mag.shape != mref.shape:
+        return desc, f"shape {mag.shape} vs {mref.shape}"
+    for c in range(ch):
+        if not peaks_ok(pb[c], mref[c], pbref[c], excl):
+            return desc, "peak bins differ beyond ties"
+        if rel_l2(mag[c], mref[c]).max() > 1e-5 * np.log2(nfft):
+            return desc, f"rel-L2 {rel_l2(mag[c], mref[c]).max():.3g}"
+    return desc, None
+
+
+def case_c2c(rng):
+    l = int(rng.integers(1, 23))
+    n = 1 << l
+    batch = int(rng.integers(1, max(2, min(64, (1 << 22) // n))))
+    x = rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))
+    inv = bool(rng.integers(0, 2))
+    desc = dict(fn="fft_c2c", log2n=l, batch=batch, inverse=inv)
+    X = fft_amd.fft_c2c(x, inverse=inv)
+    ref = np.fft.ifft(x, axis=-1) if inv else np.fft.fft(x, axis=-1)
+    if np.abs(X - ref).max() / np.abs(ref).max() > 1e-12:
+        return desc, f"error {np.abs(X - ref).max() / np.abs(ref).max():.3g}"
+    return desc, None
+
+
+def case_anylen(rng):
+    n = int(rng.integers(2, 6000))
+    batch = int(rng.integers(1, 6))
+    win = WINDOWS[rng.integers(0, 5)]
+    wp = float(n / 6) if win == "gaussian" else 0.0
+    x = rng.standard_normal((batch, n))
+    desc = dict(fn="fft_mag", n=n, batch=batch, win=win)
+    mag, pb, pm = fft_amd.fft_mag(x, window=win, win_param=wp)
+    w = O.window(win, n, wp)
+    ref = np.abs(np.fft.fft(x * w, axis=1))[:, : n // 2 + 1]
+    if (np.abs(mag - ref) / ref.max(axis=1, keepdims=True)).max() > 1e-12:
+        return desc, f"error {(np.abs(mag - ref) / ref.max(axis=1, keepdims=True)).max():.3g}"
+    if not peaks_ok(pb, ref, np.argmax(ref, axis=1), False):
+        return desc, "peak bins differ beyond ties"
+    return desc, None
+
+
+CASES = [(case_rfft, 0.5), (case_stft, 0.25), (case_c2c, 0.15), (case_anylen, 0.10)]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time(); last = t0
+    counts, fails = {}, []
+    i = 0
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, i])
+        r = rng.random(); acc = 0.0
+        for fn, p in CASES:
+            acc += p
+            if r < acc:
+                break
+        try:
+            desc, err = fn(rng)
+        except Exception as e:  # a raised error is a failure of the case, not of the soak
+            desc, err = dict(fn=fn.__name__), f"{type(e).__name__}: {e}"
+        counts[desc["fn"]] = counts.get(desc["fn"], 0) + 1
+        if err:
+            fails.append(dict(case=i, seed=seed, err=err, **desc))
+            print("FAIL", json.dumps(fails[-1]), flush=True)
+        i += 1
+        if time.time() - last > 20:
+            last = time.time()
+            print(f"[{last - t0:5.0f}s] {i} cases, {len(fails)} failures", flush=True)
+    print(json.dumps(dict(cases=i, by_entry=counts, failures=len(fails), seed=seed, seconds=round(time.time() - t0, 1))))
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
