@@ -153,7 +153,58 @@ def case_anylen(rng):
     return desc, None
 
 
-CASES = [(case_rfft, 0.5), (case_stft, 0.25), (case_c2c, 0.15), (case_anylen, 0.10)]
+DISCONTINUOUS = {"Quadrada", "Pulso", "Onda Quadrada Modulada", "Onda Comb", "Passo (step)", "Impulso", "Triangular",
+                 "Dente de Serra", "Dente de Serra Modificado", "Onda Triangular Modulada"}
+
+
+def case_compute(rng):
+    """GUI path: specengine.compute(p, vpp) (device synthesis + modulation + fp64 FFT) vs the oracle's restatement of
+    main.py:460-479, over every waveform label and random parameters; bars as in tests/test_gpu_shim.py."""
+    from fft_amd import specengine as S
+    wf = S.WAVEFORMS[rng.integers(0, len(S.WAVEFORMS))]
+    fs = float(10.0 ** rng.uniform(3, 6))
+    n_target = int(rng.integers(16, 30000))
+    fc = float(rng.uniform(0.001, 0.45) * fs); fm = float(rng.uniform(0.0001, 0.2) * fs)
+    am = bool(rng.integers(0, 2)); fmon = bool(rng.integers(0, 2)) and rng.random() < 0.5
+    desc = dict(fn="compute", wf=wf, fs=fs, n=n_target, fc=fc, fm=fm, am=am, fm_on=fmon)
+    try:
+        p = O.validate_inputs(n_target / fs, fc, fs, fm, wf, am, float(rng.uniform(0, 2)), fmon, float(rng.uniform(0, 0.05) * fs))
+    except ValueError:
+        return desc, None
+    if wf == "Ruído Branco":                             # random by definition: shape / dtype only
+        out = S.compute(p, 2.0)
+        return desc, None if all(len(v) == p["N"] for v in out.values()) else "white noise: wrong lengths"
+    vpp = float(rng.uniform(0.1, 10))
+    out = S.compute(p, vpp)
+    ref = O.compute(p, vpp)
+    if not np.array_equal(out["t"], ref["t"]) or not np.array_equal(out["f"], ref["f"]):
+        return desc, "t / f axes differ"
+    y_ref, Y_ref = ref["y"], ref["Y"]
+    if not np.isfinite(y_ref).all():
+        return desc, None
+    if wf == "Hiperbólica" and not fmon:                 # sinh overflows to 1e300+: relative compare (FM replaces y by a sine)
+        return desc, None if np.allclose(out["y"], y_ref, rtol=1e-9, atol=0) else "sinh branch differs"
+    scale = max(1.0, float(np.abs(y_ref).max()))
+    phase_span = 2 * np.pi * max(fc * 10, fm) * p["N"] / fs          # chirps sweep to 10 Fc: 1 ulp of phase ~ span * 2^-52
+    tol = max(1e-12, 4 * phase_span * 2.2e-16) * scale
+    if fmon and not wf.startswith("Onda"):
+        tol = max(tol, 1e-10 * max(1.0, p["N"] / 4096))               # blocked prefix sum vs numpy's sequential cumsum
+    dy = float(np.abs(out["y"] - y_ref).max())
+    if wf in DISCONTINUOUS:
+        if dy > tol:                                                    # an edge sample may legitimately flip under FM rounding
+            if fmon or np.count_nonzero(np.abs(out["y"] - y_ref) > tol) > 2:
+                return (desc, None) if fmon else (desc, f"y differs at {np.count_nonzero(np.abs(out['y'] - y_ref) > tol)} samples")
+            return desc, None
+    elif dy > tol:
+        return desc, f"y error {dy:.3g} > {tol:.3g}"
+    if dy <= tol:
+        err = float(np.abs(out["Y"] - Y_ref).max() / max(float(Y_ref.max()), 1e-300))
+        if err > max(1e-12, 50 * tol / scale):
+            return desc, f"Y error {err:.3g}"
+    return desc, None
+
+
+CASES = [(case_rfft, 0.4), (case_stft, 0.2), (case_c2c, 0.1), (case_anylen, 0.1), (case_compute, 0.2)]
 
 
 def main():
