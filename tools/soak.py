@@ -204,7 +204,35 @@ def case_compute(rng):
     return desc, None
 
 
-CASES = [(case_rfft, 0.4), (case_stft, 0.2), (case_c2c, 0.1), (case_anylen, 0.1), (case_compute, 0.2)]
+def case_analyze(rng):
+    """sa_analyze_frames_* (for 4096-point fp32 frames the fused kernel) vs the separate entry points and the oracle's
+    time statistics / spectral metrics, with the checkers of tests/test_gpu_metrics.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_metrics import _check_spec_metrics, _check_time_stats
+    from fft_amd import specengine as S
+    dtype = np.float32 if rng.random() < 0.7 else np.float64
+    n = 4096 if rng.random() < 0.5 else 1 << int(rng.integers(5, 14))
+    batch = int(rng.integers(1, 300))
+    win = ["none", "hann", "hamming", "blackman", "gaussian"][rng.integers(0, 5)]
+    wp = float(n / 6) if win == "gaussian" else 0.0
+    fs = float(10.0 ** rng.uniform(3, 6))
+    t = np.arange(n) / fs
+    f0 = rng.uniform(0.01, 0.2, size=(batch, 1)) * fs
+    x = (rng.uniform(0.1, 3) * np.sin(2 * np.pi * f0 * t + rng.uniform(0, 6.28, (batch, 1))) + rng.uniform(0, 0.5) * np.sin(2 * np.pi * 2 * f0 * t)
+         + rng.uniform(0, 0.3) * np.sin(2 * np.pi * 3 * f0 * t) + 10.0 ** rng.uniform(-4, -1) * rng.standard_normal((batch, n))
+         + rng.uniform(-1, 1)).astype(dtype)
+    desc = dict(fn="analyze_frames", dtype=str(np.dtype(dtype)), n=n, batch=batch, win=win, fs=fs)
+    ts, sm, pb, pm = S.analyze_frames(x, fs, win, wp)
+    mag, pb2, pm2 = fft_amd.rfft_peak(x, win, wp)
+    if not (np.array_equal(pb, pb2) and np.array_equal(pm, pm2)):
+        return desc, "peak differs from rfft_peak"
+    for b in np.unique(np.r_[0, batch - 1, rng.integers(0, batch, 6)]):
+        _check_time_stats(ts[b], x[b].astype(np.float64))
+        _check_spec_metrics(sm[b], mag[b].astype(np.float64), n, fs / n)
+    return desc, None
+
+
+CASES = [(case_analyze, 0.1), (case_rfft, 0.3), (case_stft, 0.2), (case_c2c, 0.1), (case_anylen, 0.1), (case_compute, 0.2)]
 
 
 def main():
