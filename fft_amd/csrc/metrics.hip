@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(MT) spectral_metrics_wave_kernel(const T* __re
 // fp32 frames of 256 NL samples (NL = 1 .. 16) whose rows are 16-byte aligned: the frame is loaded once as NL
 // 16-byte loads per lane and both passes run on registers (time_stats_regs, metrics_row.h) — about half the
 // instructions of the sweep kernel above, and no second read.
-template <int NL>
+template <int NL, bool NT = false>
 __global__ void __launch_bounds__(MT) time_stats_regs_kernel(const float* __restrict__ y, int64_t batch, int64_t stride,
                                                              sa_time_stats* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(MT) time_stats_regs_kernel(const float* __rest
         const v4f* x4 = reinterpret_cast<const v4f*>(y + f * stride);
         v4f r[NL];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) r[j] = x4[64 * j + lane];
+        for (int j = 0; j < NL; ++j) r[j] = NT ? __builtin_nontemporal_load(x4 + 64 * j + lane) : x4[64 * j + lane];
         const sa_time_stats t = time_stats_regs<NL>(r, lane);
         if (lane == 0) out[f] = t;
     }
@@ -508,13 +508,17 @@ static bool launch_regs_kernel(const double*, int64_t, int64_t, int64_t, sa_time
 static bool launch_regs_kernel(const float* y, int64_t batch, int64_t n, int64_t stride, sa_time_stats* out, hipStream_t st) {
     if ((reinterpret_cast<uintptr_t>(y) & 15) || (stride & 3)) return false;
     const dim3 grid(grid_for((batch + MW - 1) / MW)), block(MT);
+    // frames are read once: nontemporal loads (SA_METRICS_NT=0, tuning aid, keeps the default policy)
+    static const bool nt = getenv("SA_METRICS_NT") ? atoi(getenv("SA_METRICS_NT")) != 0 : true;
+#define SA_TS_CASE(N, NLV)                                                                                              \
+    case N:                                                                                                             \
+        if (nt) hipLaunchKernelGGL((time_stats_regs_kernel<NLV, true>), grid, block, 0, st, y, batch, stride, out);     \
+        else hipLaunchKernelGGL((time_stats_regs_kernel<NLV, false>), grid, block, 0, st, y, batch, stride, out);       \
+        return true;
     switch (n) {
-        case 256: hipLaunchKernelGGL(time_stats_regs_kernel<1>, grid, block, 0, st, y, batch, stride, out); return true;
-        case 512: hipLaunchKernelGGL(time_stats_regs_kernel<2>, grid, block, 0, st, y, batch, stride, out); return true;
-        case 1024: hipLaunchKernelGGL(time_stats_regs_kernel<4>, grid, block, 0, st, y, batch, stride, out); return true;
-        case 2048: hipLaunchKernelGGL(time_stats_regs_kernel<8>, grid, block, 0, st, y, batch, stride, out); return true;
-        case 4096: hipLaunchKernelGGL(time_stats_regs_kernel<16>, grid, block, 0, st, y, batch, stride, out); return true;
+        SA_TS_CASE(256, 1) SA_TS_CASE(512, 2) SA_TS_CASE(1024, 4) SA_TS_CASE(2048, 8) SA_TS_CASE(4096, 16)
     }
+#undef SA_TS_CASE
     return false;
 }
 
