@@ -80,16 +80,21 @@ static bool r4k_nt() {
 template <int MODE>
 static int launch_r4k(const RfftArgs<float>& a, hipStream_t st) {
     if (r4k_variant() == 1) return launch_r4k_v<MODE, 12, true>(a, st);
-    // Spectra written, symmetric window: one-shot 4-wave workgroups on the half window table (rfft4096.h, VAR = 3),
-    // three to a CU — their set-up, load latency and drain overlap each other's arithmetic.  Measured at 2^20 / 2^18
-    // frames (M spectra/s; profiles/r01_wg_shape_ab.txt): this 227 / 215-217; one looping 16-wave workgroup per CU
-    // 223-224 / 208; 8-wave one-shot (two per CU) 217 / 224; 8-wave looping 214 / 225 (the 8-wave forms are no longer
-    // instantiated).  SA_R4K_WH=0 (tuning aid) selects the looping 16-wave workgroup.
-    static const int wh = getenv("SA_R4K_WH") ? atoi(getenv("SA_R4K_WH")) : 6;
+    // Spectra written, symmetric window: one-shot 3-wave workgroups on the half window table (rfft4096.h, VAR = 3),
+    // four to a CU (36.5 KiB of LDS each) — their set-up, load latency and drain overlap each other's arithmetic.
+    // Measured at 2^20 / 2^18 frames (M spectra/s; profiles/r01_wg_shape_ab.txt, same box per line group):
+    //   one-shot 3-wave 227-228 / 213-214, 4-wave 224 / 213, 2-wave 219 / 203, 6-wave 217 / 204;
+    //   earlier box: 4-wave one-shot 227 / 215-217, one looping 16-wave workgroup per CU 223-224 / 208, 8-wave
+    //   one-shot (two per CU) 217 / 224, 8-wave looping 214 / 225.
+    // SA_R4K_WH (tuning aid): 3 = default, 6 = 4-wave one-shot, 0 = the looping 16-wave workgroup.
+    static const int wh = getenv("SA_R4K_WH") ? atoi(getenv("SA_R4K_WH")) : 3;
     // (peak-only mode measured 286 M/s in the one-shot form against 291 M/s looping: it stays persistent)
     if constexpr (MODE != 0) {
         if (a.win_sym && r4k_nt()) {
-            if (wh == 6) return launch_r4k_v<MODE, 4, false, 0, R4K_NT_STREAM, 3>(a, st);
+            if (wh == 3) return launch_r4k_v<MODE, 3, false, 0, R4K_NT_STREAM, 3>(a, st);
+            if constexpr (MODE == 1) {
+                if (wh == 6) return launch_r4k_v<MODE, 4, false, 0, R4K_NT_STREAM, 3>(a, st);
+            }
         }
     }
     if (r4k_nt()) return launch_r4k_v<MODE, 16, false, 0, R4K_NT_STREAM>(a, st);
@@ -251,6 +256,7 @@ int rfft4096_metrics_dev(const float* x, int64_t batch, int32_t window, double w
     // workgroups share a CU: all metrics 9.58 -> 8.66 ms, statistics + peak 6.63 -> 6.37 ms, spectral metrics + peak
     // 5.86 -> 5.87 ms at 2^20 frames.  SA_R4K_FUSE_WH=0 (tuning aid) selects the looping 16-wave form.
     static const int fuse_wh = getenv("SA_R4K_FUSE_WH") ? atoi(getenv("SA_R4K_FUSE_WH")) : 1;
+    // (3-wave workgroups, the headline kernel's shape, measured 9.44 ms here against 8.82 ms for 4-wave ones)
     if (fuse_wh && r4k_nt() && a.win_sym) {
         if (fuse == 1) return launch_r4k_v<0, 4, false, 1, R4K_NT_STREAM, 3>(a, st, fz);
         if (fuse == 2) return launch_r4k_v<0, 4, false, 2, R4K_NT_STREAM, 3>(a, st, fz);
