@@ -167,3 +167,32 @@ def test_host_path_pipelined_chunks_match_single_chunk():
     m1, b1, _ = fft_amd.rfft_peak(x64[2048:4096], "hamming")
     np.testing.assert_array_equal(m64[2048:4096], m1)
     np.testing.assert_array_equal(b64[2048:4096], b1)
+
+
+def test_wave_kernel_variants_agree_bitwise(tmp_path):
+    """The 4096-point kernel has several launch forms (one-shot 3-wave workgroups on the half window table — the
+    default —, 4-wave, the looping 16-wave workgroup on the full table; nontemporal or default-policy accesses).
+    Same arithmetic in all of them: spectra, dB spectra and peaks must be bit-identical.  The forms are chosen by
+    environment variables read once per process, so the others run in child processes."""
+    import subprocess
+    import sys
+    import fft_amd
+    rng = np.random.default_rng(4096)
+    x = rng.standard_normal((777, 4096)).astype(np.float32)
+    np.save(tmp_path / "x.npy", x)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import fft_amd; x = np.load(sys.argv[1]);"
+        "m, pb, pm = fft_amd.rfft_peak(x, 'hann'); d, pbd, _ = fft_amd.rfft_peak(x, 'blackman', db=True, exclude_dc_nyq=True);"
+        "np.savez(sys.argv[2], m=m, pb=pb, pm=pm, d=d, pbd=pbd)" % root)
+    ref = dict(zip(("m", "pb", "pm"), fft_amd.rfft_peak(x, "hann")))
+    ref["d"], ref["pbd"], _ = fft_amd.rfft_peak(x, "blackman", db=True, exclude_dc_nyq=True)
+    for i, env in enumerate(({"SA_R4K_WH": "0"}, {"SA_R4K_WH": "0", "SA_R4K_NT": "0"}, {"SA_R4K_WH": "6"})):
+        out = tmp_path / f"v{i}.npz"
+        subprocess.run([sys.executable, "-c", child, str(tmp_path / "x.npy"), str(out)], check=True, timeout=100,
+                       env={**os.environ, **env})
+        z = np.load(out)
+        for k in ("m", "pb", "pm", "pbd"):
+            np.testing.assert_array_equal(z[k], ref[k], err_msg=f"{env} {k}")
+        if env.get("SA_R4K_WH") != "6":
+            np.testing.assert_array_equal(z["d"], ref["d"], err_msg=f"{env} d")     # (the dB kernel has no 4-wave form)
