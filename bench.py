@@ -49,7 +49,10 @@ def cpu_baseline(x_sample, budget_s=12.0):
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
         ncores = os.cpu_count() or 1
-    ncores_used = min(ncores, 16)
+    # threads actually used: this job's CPU share (the GPU box exports it as OMP_NUM_THREADS; nproc there shows the
+    # whole machine), else every core the process may run on
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    ncores_used = min(ncores, int(share)) if share.isdigit() and int(share) > 0 else ncores
     w32 = w.astype(np.float32)
     chunk = x_sample[:2048]
     t0 = time.perf_counter(); cnt = 0
@@ -58,8 +61,9 @@ def cpu_baseline(x_sample, budget_s=12.0):
         Y.argmax(axis=1)
         cnt += len(chunk)
     best = cnt / (time.perf_counter() - t0)
-    return {"value": best, "unit": "spectra/s", "cores": ncores_used, "kind": "port",
-            "sample": f"{len(chunk)}-frame chunks of the same device-generated C2 frames, scipy.fft.rfft fp32 workers={ncores_used} "
+    return {"value": best, "unit": "spectra/s", "cores": ncores_used, "kind": "reference",
+            "sample": f"scipy.fft (pocketfft) is the library the reference itself calls for this path (main.py:475; there is no "
+                      f"reference-native code to compile); {len(chunk)}-frame chunks of the same device-generated C2 frames, scipy.fft.rfft fp32 workers={ncores_used} "
                       f"+abs+argmax for ~{budget_s * 2 / 3:.0f}s; reference 1-thread fp64 fft pattern = {ref1t:.0f} spectra/s",
             "ref_1thread_fp64": ref1t, "host_cpus_visible": ncores}
 
@@ -72,24 +76,50 @@ def main():
     ap.add_argument("--log2-batch", type=int, default=20, help="frames per GPU = 2^k (default 2^20 = config C2)")
     ap.add_argument("--peak-only", action="store_true", help="mode B: no spectrum written")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="rendezvous, barrier and max-over-ranks only (no GPU work, value = null): CPU test of the launch path")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes now, before this process
+        # has imported torch or touched the GPU (a process that has initialised the GPU must never exec another program),
+        # relay rank 0's JSON line and leave with the children's exit code.
+        sys.exit(_launch_ranks(args.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     # Rehearsal aid for a one-GPU box (not used by the driver): SA_BENCH_SHARE_GPU=1 puts every rank on device 0
     # and swaps RCCL (which refuses two ranks on one device) for gloo; the timed region is unchanged.
-    share = os.environ.get("SA_BENCH_SHARE_GPU") == "1"
+    share = os.environ.get("SA_BENCH_SHARE_GPU") == "1" or args.plumbing_only
     dev = 0 if share else local_rank
-    torch.cuda.set_device(dev)
+    if not args.plumbing_only:
+        torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    if args.plumbing_only:
+        elapsed = 1.0 + rank
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "plumbing only (no GPU work)", "value": None, "unit": "spectra/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "max_rank_elapsed": elapsed}))
+        return
 
     from fft_amd import _lib
     lib = _lib.load()
@@ -137,6 +167,11 @@ def main():
                                               max(args.steps, 5), C.byref(ms)))
     alg = ALG_BYTES_B if args.peak_only else ALG_BYTES_A
     achieved = alg * batch / (ms.value * 1e-3) / 1e9
+    # mode B (peak only, SURVEY §8(d) C2: 16 392 B/frame) timed the same way in the same run
+    ms_b = C.c_float(0)
+    _lib.check(lib.sa_time_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, 0, None, dpb.ptr, dpm.ptr,
+                                              max(args.steps, 5), C.byref(ms_b)))
+    achieved_b = ALG_BYTES_B * batch / (ms_b.value * 1e-3) / 1e9
     # HBM traffic per launch from the PMC passes archived under profiles/ (rocprofv3 cannot run inside
     # the bench): FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, scaled to this launch's frame count.
     traffic = None
@@ -175,6 +210,9 @@ def main():
                          "alg_bytes_per_launch": alg * batch,
                          "alg_bytes_per_frame": alg, "kernel_ms": ms.value},
             "parity_sample_ok": parity_ok,
+            "extra": {"mode_b_peak_only": {"spectra_per_s_per_gpu": batch / (ms_b.value * 1e-3), "kernel_ms": ms_b.value,
+                                           "achieved_GBps": achieved_b, "frac": achieved_b / HBM_PEAK_GBS,
+                                           "alg_bytes_per_frame": ALG_BYTES_B}},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(xs if ns >= 2048 else _more_frames(dx, n))
@@ -182,6 +220,39 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _launch_ranks(n_gpus):
+    """Start `n_gpus` ranks of this script under torch.distributed.run as a child process group and relay the result."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        try:
+            j = json.loads(ln)
+        except ValueError:
+            print(ln, file=sys.stderr)
+            continue
+        if isinstance(j, dict) and "n_gpus" in j:
+            line = (ln, j)
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line[0], flush=True)
+    if proc.returncode != 0:
+        return proc.returncode
+    if line is None or line[1]["n_gpus"] != n_gpus:
+        print(f"bench.py: expected one JSON line with n_gpus == {n_gpus}, got {line[1]['n_gpus'] if line else 'none'}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def _more_frames(dx, n, ns=2048):

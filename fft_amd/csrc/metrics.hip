@@ -269,7 +269,12 @@ __global__ void __launch_bounds__(MT) find_peaks_kernel(const T* __restrict__ xa
                 for (int c = threadIdx.x; c < cnt; c += MT)
                     if (state[c] == 3) state[c] = 1;
                 __syncthreads();
-                if (!s_any) break;
+                // every wave reads the flag into a register BEFORE anyone may clear it for the next round (a wave
+                // that looped round first would otherwise reset it under the others, who then leave early and pair
+                // their barriers with a different code path)
+                const int again = s_any;
+                __syncthreads();
+                if (!again) break;
             }
             // 3. ordered compaction of the kept peaks (write position never passes the read position)
             int kept = 0;

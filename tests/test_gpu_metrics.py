@@ -176,6 +176,26 @@ def test_find_peaks_plateaus_and_edges():
         S.find_peaks(np.zeros((2, 2)))
 
 
+@pytest.mark.parametrize("distance", [2, 10, 33])
+def test_find_peaks_many_rows_many_candidates(distance):
+    """Thousands of candidates per row, many rows, distance > 1: every suppression round ends on a workgroup-wide
+    flag (a wave that looped round first used to clear it under the others).  Index lists vs scipy."""
+    import scipy.signal as ss
+    lib = _lib.load()
+    rng = np.random.default_rng(4242 + distance)
+    batch, n = 384, 16384
+    x = rng.standard_normal((batch, n))
+    x[::3] += np.sin(np.arange(n) * 0.01) * 3                         # long monotone stretches: many rounds
+    mp = n // 2
+    idx = np.empty((batch, mp), np.int32); cnt = np.empty(batch, np.int32)
+    for _ in range(3):                                                 # the window was narrow: repeat
+        _lib.check(lib.sa_find_peaks_f64(_lib.ptr(x), batch, n, -np.inf, 0.0, distance, mp, _lib.ptr(idx), _lib.ptr(cnt)))
+        for b in range(batch):
+            ref = ss.find_peaks(x[b], distance=distance)[0]
+            assert cnt[b] == len(ref), (b, cnt[b], len(ref))
+            np.testing.assert_array_equal(idx[b, :cnt[b]], ref, err_msg=f"row {b}")
+
+
 def _check_spec_metrics(m, half, n, step):
     ref = O.spectral_metrics(half, n, step)
     for k in ("fund_bin", "harm_lo_bin", "n_peaks", "top_peak_bin", "bw_lo_bin", "bw_hi_bin"):

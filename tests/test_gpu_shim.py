@@ -9,7 +9,11 @@ from fft_amd import specengine as S
 
 pytestmark = pytest.mark.gpu
 
-DISCONTINUOUS = {"Quadrada", "Pulso", "Onda Quadrada Modulada", "Onda Comb", "Passo (step)", "Impulso"}
+def _near_tie(Y, rel=1e-9):
+    """np.argmax of the reference spectrum is decided by less than `rel` (e.g. the two mirror twins differ by rounding,
+    or two bins tie): either index is then a faithful read-out."""
+    top = np.sort(Y[np.isfinite(Y)])[-2:]
+    return len(top) == 2 and (top[1] - top[0]) <= rel * max(top[1], 1e-300)
 
 
 def test_compute_matches_reference_last_data(golden_dir):
@@ -17,6 +21,7 @@ def test_compute_matches_reference_last_data(golden_dir):
     z = np.load(os.path.join(golden_dir, "ref_compute.npz"))
     meta = json.load(open(os.path.join(golden_dir, "ref_compute.json"), encoding="utf-8"))
     worst = 0.0
+    checked = nonfinite = 0
     for case in meta["cases"]:
         key, p, vpp = case["key"], case["p"], case["vpp"]
         y_ref, Y_ref = z[key + "_y"], z[key + "_Y"]
@@ -26,29 +31,44 @@ def test_compute_matches_reference_last_data(golden_dir):
         np.testing.assert_array_equal(out["t"], z[ci + "_t"])
         np.testing.assert_array_equal(out["f"], z[ci + "_f"])
         wf = p["waveform"]
-        if not np.isfinite(y_ref).all():                 # Rampa/Parábola never hit this; guard only
+        # FM REPLACES y by sin(phase) whatever the base waveform (main.py:623-627), unless the waveform is one of the
+        # pre-modulated "Onda AM*" / "Onda FM*" names, for which _apply_modulation is skipped (main.py:471)
+        fm = bool(p["fm_on"]) and not wf.startswith(("Onda AM", "Onda FM"))
+        checked += 1
+        if not np.isfinite(y_ref).all():
+            # sinh overflow (Hiperbólica at 2 pi Fc t > 709): same +-inf samples, the finite ones as below, and the
+            # spectrum non-finite in the same places with the same np.argmax read-out (first NaN)
+            assert wf == "Hiperbólica" and not fm, key
+            fin = np.isfinite(y_ref)
+            np.testing.assert_array_equal(np.isfinite(out["y"]), fin, err_msg=key)
+            np.testing.assert_array_equal(out["y"][~fin], y_ref[~fin], err_msg=key)            # same signed infinities
+            np.testing.assert_allclose(out["y"][fin], y_ref[fin], rtol=1e-9, atol=0, err_msg=key)
+            np.testing.assert_array_equal(np.isnan(out["Y"]), np.isnan(Y_ref), err_msg=key)
+            np.testing.assert_array_equal(np.isinf(out["Y"]), np.isinf(Y_ref), err_msg=key)
+            assert int(np.argmax(out["Y"])) == int(np.argmax(Y_ref)), key
+            nonfinite += 1
             continue
         scale = max(1.0, np.abs(y_ref).max())
-        if wf == "Hiperbólica":                          # sinh(2 pi Fc t) overflows to 1e300+: relative compare
-            np.testing.assert_allclose(out["y"], y_ref, rtol=1e-9, err_msg=key)
-            continue
-        tol = 1e-12 * scale
-        if p["fm_on"] and not wf.startswith("Onda"):
-            tol = 1e-10                                   # blocked prefix sum vs numpy's sequential cumsum
-        if wf.startswith("Chirp"):
+        if fm:
+            tol = 1e-10                                   # blocked prefix sum vs numpy's sequential cumsum; |y| <= 1
+        elif wf == "Hiperbólica":
+            tol = 1e-9 * scale                            # sinh at arguments up to ~700: relative error = absolute error of the argument
+        elif wf.startswith("Chirp"):
             tol = 2e-11                                   # phase reaches ~1e4 rad: 1 ulp of phase (t**3 via pow in numpy) ~ 2e-12
-        if wf in DISCONTINUOUS or wf in ("Triangular", "Dente de Serra", "Dente de Serra Modificado", "Onda Triangular Modulada"):
-            # same sample-exact edges as numpy (phase and fmod are evaluated in numpy's order)
-            if not p["fm_on"]:
-                assert np.abs(out["y"] - y_ref).max() <= tol, (key, wf)
         else:
-            assert np.abs(out["y"] - y_ref).max() <= tol, (key, wf, np.abs(out["y"] - y_ref).max())
+            tol = 1e-12 * scale                           # incl. the discontinuous waveforms: sample-exact edges (phase and
+                                                          # fmod are evaluated in numpy's order)
+        dy = np.abs(out["y"] - y_ref).max()
+        assert dy <= tol, (key, wf, dy, tol)                                   # every waveform x modulation, unconditionally
+        if wf == "Hiperbólica" and not fm:
+            np.testing.assert_allclose(out["y"], y_ref, rtol=1e-9, atol=1e-300, err_msg=key)   # per sample, over 270 decades
+        # |dY[k]| <= sum |dy| <= N dy; relative to the largest bin (>= the largest |y| by Parseval) the y bar carries over
         err = np.abs(out["Y"] - Y_ref).max() / max(Y_ref.max(), 1e-300)
-        if np.abs(out["y"] - y_ref).max() <= tol:
-            assert err < max(1e-12, 50 * tol), (key, wf, err)
-            worst = max(worst, err)
+        assert err < max(1e-12, 50 * tol / scale), (key, wf, err)               # unconditional
+        assert int(np.argmax(out["Y"])) == int(np.argmax(Y_ref)) or _near_tie(Y_ref), key
+        worst = max(worst, err)
         np.testing.assert_array_equal(out["Y"][1:], out["Y"][1:][::-1])      # exact Hermitian mirror (even N)
-    assert worst < 1e-10
+    assert worst < 1e-8 and checked == len(meta["cases"]) == 165 and nonfinite >= 1
 
 
 def test_config1_through_the_shim(golden_dir):
