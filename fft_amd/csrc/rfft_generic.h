@@ -165,9 +165,19 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                 const C zq = pq[lds_pad_c<S>(TPF * u)];
                 const C zm = buf[(tq == 0 ? m0 : mlow) + moff];
                 // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
-                const C e = mk<T>(HALF * (zq.x + zm.x), HALF * (zq.y - zm.y));
+                const C e0 = mk<T>(HALF * (zq.x + zm.x), HALF * (zq.y - zm.y));
                 const C d = mk<T>(HALF * (zq.x - zm.x), HALF * (zq.y + zm.y));
-                const C wo = cmul(mk<T>(d.y, -d.x), tn[u]);
+                C wo = cmul(mk<T>(d.y, -d.x), tn[u]);
+                C e = e0;
+                if (u == 0) {
+                    // q = 0: X[0] = Re Z0 + Im Z0 and X[M] = Re Z0 - Im Z0 exactly.  Finite data give the same bits either
+                    // way; with overflowed samples (the reference's Hiperbólica reaches sinh = inf, main.py:586) the general
+                    // formula would turn DC into inf - inf = NaN where the reference's plain sum reads +-inf.
+                    const bool dc = tq == 0;
+                    e.y = dc ? (T)0 : e.y;
+                    wo.x = dc ? d.y : wo.x;
+                    wo.y = dc ? (T)0 : wo.y;
+                }
                 const C xa = cadd(e, wo);            // X[q]
                 const C xb = csub(e, wo);            // conj(X[M-q])
                 const T ma = mag_sqrt(xa.x * xa.x + xa.y * xa.y);
