@@ -59,6 +59,7 @@ PROTOTYPES = {
     "sa_time_stats_f64_dev": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "sa_find_peaks_f64": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _i32, _i32, _vp, _vp]),
     "sa_find_peaks_f64_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "sa_find_peaks_f64_noalloc_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _i32, _i32, _vp, _vp, _vp]),
     "sa_spectral_metrics_f64": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp]),
     "sa_spectral_metrics_f32_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),
     "sa_spectral_metrics_f64_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),

@@ -19,6 +19,7 @@
 
 #include "metrics_row.h"
 #include "runtime.h"
+#include <atomic>
 
 namespace sa {
 
@@ -576,9 +577,53 @@ static int find_peaks_dev(const double* x, int64_t batch, int64_t n, double heig
     return SA_OK;
 }
 
+// ---- allocation-free find_peaks: the `work` bytes of sa_find_peaks_f64_dev live in a file-scope device array ----
+// For callers that cannot allocate (HIP graph capture, tight serving loops).  The array's NAME is only a host-side
+// stand-in; its device address is looked up once per device with hipGetSymbolAddress (every GPU holds its own copy at
+// its own address) and from then on only that pointer is handed to kernels.
+static __device__ __align__(256) uint8_t scratch[SA_NOALLOC_SCRATCH_BYTES];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::atomic<uint8_t*> g_scratch_ptr[NOALLOC_MAX_DEVICES];
+
+// Once per device, with that device current (sa_init, and the entry point's first call on a device).
+int noalloc_setup_current_device(uint8_t** out) {
+    int dev = 0;
+    SA_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) { set_error("no-alloc scratch: device %d out of range", dev); return SA_EUNSUP; }
+    uint8_t* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        void* sym = nullptr;
+        SA_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));
+        if (!sym) { set_error("no-alloc scratch: hipGetSymbolAddress returned NULL on device %d", dev); return SA_EHIP; }
+        p = static_cast<uint8_t*>(sym);
+        g_scratch_ptr[dev].store(p, std::memory_order_release);      // racing threads store the same address
+    }
+    if (out) *out = p;
+    return SA_OK;
+}
+
 }  // namespace sa
 
 extern "C" {
+
+int sa_find_peaks_f64_noalloc_dev(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel,
+                                  int32_t distance, int32_t max_peaks, int32_t* idx, int32_t* count, void* stream) {
+    using namespace sa;
+    if (!initialised()) { set_error("find_peaks_noalloc: call sa_init first (this entry point sets nothing up that could allocate)"); return SA_EINVAL; }
+    if (!stream) { set_error("find_peaks_noalloc: pass the stream to enqueue on (hipStreamLegacy = (void*)1 for the null stream)"); return SA_EINVAL; }
+    if (batch < 0 || n < 1 || max_peaks < 1 || distance < 1) {
+        set_error("find_peaks: need batch >= 0, n >= 1, max_peaks >= 1, distance >= 1");
+        return SA_EINVAL;
+    }
+    if ((uint64_t)batch * (uint64_t)max_peaks > (uint64_t)SA_NOALLOC_SCRATCH_BYTES) {
+        set_error("find_peaks_noalloc: batch * max_peaks = %lld exceeds the built-in scratch of %lld bytes; use "
+                  "sa_find_peaks_f64_dev with a work buffer", (long long)batch * max_peaks, (long long)SA_NOALLOC_SCRATCH_BYTES);
+        return SA_EUNSUP;
+    }
+    uint8_t* work = nullptr;
+    SA_TRY(noalloc_setup_current_device(&work));
+    return find_peaks_dev(x, batch, n, height_abs, height_rel, distance, max_peaks, idx, count, work, (hipStream_t)stream);
+}
 
 int sa_time_stats_f32_dev(const float* y, int64_t batch, int64_t n, int64_t frame_stride, sa_time_stats* out, void* stream) {
     SA_TRY(sa::ensure_init());

@@ -13,6 +13,10 @@ namespace sa {
 
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 int ensure_init();                 // SA_OK or error (message set)
+bool initialised();                // ensure_init has succeeded in this process
+// metrics.hip: resolves the device address of the allocation-free entry point's scratch array on the CURRENT device
+// (once per device; returns it in *out when out != nullptr)
+int noalloc_setup_current_device(uint8_t** out);
 hipStream_t thread_stream();       // the calling thread's library stream on the current device
 int num_cus();                     // multiprocessor count of the current device
 // Raise a kernel's dynamic-LDS limit on the current device once (the attribute is per device, and a thread may

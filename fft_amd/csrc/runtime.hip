@@ -27,6 +27,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int num_cus() { return g_ncus; }
+bool initialised() { return g_inited.load(std::memory_order_acquire); }
 
 int64_t grid_cap(int per_cu, const char* family) {
     char name[64];
@@ -387,7 +388,10 @@ int sa_set_device(int device) {
 
 int sa_init(int device) {
     if (device >= 0) SA_HIP(hipSetDevice(device));
-    return sa::ensure_init();
+    SA_TRY(sa::ensure_init());
+    // per-device set-up of the allocation-free entry point's scratch (metrics.hip); sa_init may be called once per
+    // device a process uses, each call with that device current
+    return sa::noalloc_setup_current_device(nullptr);
 }
 
 void sa_shutdown(void) {

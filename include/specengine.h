@@ -237,6 +237,20 @@ int sa_find_peaks_f64_dev(const double* x, int64_t batch, int64_t n, double heig
                           int32_t distance, int32_t max_peaks, int32_t* idx, int32_t* count, uint8_t* work,
                           void* stream);
 
+/* Allocation-free variant of sa_find_peaks_f64_dev.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory — code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same arguments, results and kernels as sa_find_peaks_f64_dev, but the `work` bytes come from a device array built
+ * into the library (SA_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends) instead of the caller:
+ *   - batch * max_peaks must be <= SA_NOALLOC_SCRATCH_BYTES, else SA_EUNSUP (use sa_find_peaks_f64_dev);
+ *   - sa_init must have succeeded before (SA_EINVAL otherwise) and `stream` must be given ((void*)1 = the null
+ *     stream): the call itself creates no stream and calls no hipMalloc / hipFree / allocating routine;
+ *   - every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (different streams or
+ *     threads) race — serialise them.  Nothing needs clearing between calls (the kernel initialises each state byte
+ *     it reads). */
+#define SA_NOALLOC_SCRATCH_BYTES (4 << 20)
+int sa_find_peaks_f64_noalloc_dev(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel,
+                                  int32_t distance, int32_t max_peaks, int32_t* idx, int32_t* count, void* stream);
+
 /* ---- f1: derived spectral metrics of a half spectrum (frequency half of update_analysis_panels,
  *      main.py:1619-1735) ------------------------------------------------------------------------------
  * mag [batch][n/2+1] = |Y| of length-n frames as the rfft entry points write them.  Positive bins are
