@@ -45,7 +45,13 @@ PROTOTYPES = {
     "sa_fill_tone_noise_f32_dev": (C.c_int, [_vp, _i64, _i32, _dbl, _u64, _vp]),
     "sa_fft_c2c_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i32]),
     "sa_fft_c2c_f64_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
-    "sa_twiddle_rows_f64_dev": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp]),
+    "sa_dist_plan_create": (C.c_int, [C.POINTER(_vp), _i64, _i32, _vp, _i32]),
+    "sa_dist_plan_info": (C.c_int, [_vp, _i32, _vp]),
+    "sa_dist_execute": (C.c_int, [_vp, _vp]),
+    "sa_dist_plan_destroy": (C.c_int, [_vp]),
+    "sa_dist_fill": (C.c_int, [_vp, _i32, _i64, _u64]),
+    "sa_dist_check": (C.c_int, [_vp, _i32, _i64, C.POINTER(_dbl)]),
+    "sa_fft_c2c_f64_dist": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "sa_fft_mag_f64": (C.c_int, [_vp, _i64, _i64, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "sa_synth_f64": (C.c_int, [_vp, _vp, _vp]),
     "sa_synth_analyze": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp]),
@@ -70,6 +76,29 @@ PROTOTYPES = {
     "sa_analyze_frames_f32_dev": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sa_analyze_frames_f64_dev": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+DIST_MAX_RANKS = 16
+DIST_NATURAL_IN, DIST_NATURAL_OUT = 1, 2
+DIST_XCHG_AUTO, DIST_XCHG_DMA, DIST_XCHG_KERNEL, DIST_XCHG_FUSED = 0, 1, 2, 3
+DIST_XCHG_NAMES = {"auto": 0, "dma": 1, "kernel": 2, "fused": 3}
+DIST_KAT_IMPULSE, DIST_KAT_TONE, DIST_KAT_NOISE = 0, 1, 2
+
+
+class DistInfo(C.Structure):
+    """struct sa_dist_info (include/specengine.h)."""
+    _fields_ = [("n", _i64), ("R1", _i64), ("S", _i64), ("cols_per_rank", _i64), ("rows_per_rank", _i64), ("slab_elems", _i64),
+                ("n_ranks", _i32), ("n_devices", _i32), ("device", _i32), ("exchange_mode", _i32), ("n_chunks", _i32),
+                ("reserved", _i32), ("in_", _vp), ("out", _vp)]
+
+
+class DistStats(C.Structure):
+    """struct sa_dist_stats (include/specengine.h)."""
+    _fields_ = [("n", _i64), ("bytes_per_peer", _i64), ("n_ranks", _i32), ("n_devices", _i32), ("exchange_mode", _i32),
+                ("n_chunks", _i32), ("exchanges", _i32), ("reserved", _i32), ("total_ms", _dbl), ("device_ms", _dbl),
+                ("pass1_ms", _dbl), ("phase2_ms", _dbl), ("exchange_ms", _dbl), ("link_gbps_min", _dbl),
+                ("link_gbps_mean", _dbl), ("link_gbps_max", _dbl), ("aggregate_gbps", _dbl),
+                ("link_gbps", (_dbl * DIST_MAX_RANKS) * DIST_MAX_RANKS)]
 
 
 class GenParams(C.Structure):

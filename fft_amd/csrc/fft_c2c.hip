@@ -58,7 +58,20 @@ struct C2cArgs {
     int conj_out;     // inverse transform: conjugate on store (last pass)
     double scale;     // 1/n for the inverse, else 1
     int natural;      // final pass: 1 = natural order, 0 = leave digit-reversed
+    // ---- distributed four-step (dist_fft.hip) ----
+    int64_t tw_col0;  // strided pass: global column index of local column 0 (the twiddle is w^{(tw_col0 + s) k})
+    int nt_hint;      // -1: streaming passes chosen from n * batch; 0 / 1: forced
+    // XF == 1 (blocked loads): element s of batch row b lives at in + b * blk_row + (s >> blk_shift) * blk_pitch +
+    // (s & blk_mask) — the layout the exchange delivers: one block of columns per source rank
+    int blk_shift;
+    int64_t blk_mask, blk_pitch, blk_row;
+    // XF == 2 (push stores): output row k goes to push_tab[k >> push_shift] + (k & push_mask) * push_row + column —
+    // straight into the receive buffers of the ranks that own those rows (peer-mapped pointers)
+    int push_shift;
+    int64_t push_mask, push_row;
+    Cd* const* push_tab;
 };
+enum { XF_PLAIN = 0, XF_BLK = 1, XF_PUSH = 2 };
 
 // ---- strided pass ------------------------------------------------------------------------------
 // FAR = false: the next column group's loads are issued before the twiddle/store epilogue, into the butterfly
@@ -68,7 +81,7 @@ struct C2cArgs {
 //   counter.  With one 128 KiB workgroup per CU nothing else covers the latency of 1024 x 128-byte reads 16 MiB
 //   apart: timing-only variants put that pass at 9.1 ms without the transform and 12.3 ms with it, while the
 //   second pass (rows 16 KiB apart) hides the same transform completely.
-template <int LR, int B, bool FAR, bool STREAM = false>
+template <int LR, int B, bool FAR, bool STREAM = false, int XF = XF_PLAIN>
 __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pass(C2cArgs a) {
     using PL = FftPlan<LR, C2C_PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
@@ -88,6 +101,17 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
     Cd v[P], nx[FAR ? P : 1];
     auto load_group = [&](int64_t g, Cd* d) {
         const int64_t sg = g % groups_per_a, ab = g / groups_per_a;
+        if (XF == XF_BLK) {                              // A == 1: ab is the batch row; a column group never straddles a block
+            const Cd* src = a.in + ab * a.blk_row + sg * B + col;
+#pragma unroll
+            for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+                for (int n1 = 0; n1 < R0; ++n1) {
+                    const int64_t rs = (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S;
+                    d[u * R0 + n1] = ld_c<STREAM>(&src[(rs >> a.blk_shift) * a.blk_pitch + (rs & a.blk_mask)]);
+                }
+            return;
+        }
         const int64_t base = (ab / a.A) * a.n + (ab % a.A) * (R * a.S) + sg * B + col;
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
@@ -117,11 +141,12 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
         constexpr int NU = (R * B) / NT;                 // outputs per thread (= P)
         const int c = threadIdx.x % B, k0 = threadIdx.x / B;
         const int64_t sc = sg * B + c;
+        const int64_t sct = sc + a.tw_col0;              // column index inside the whole (possibly distributed) view
         const int64_t hm = ((int64_t)1 << a.h) - 1;
         auto lookup = [&](int64_t j) { return cmul(a.thi[j >> a.h], a.tlo[j & hm]); };   // j < R * S
-        const Cd w0 = lookup(sc * k0);
+        const Cd w0 = lookup(sct * k0);
         Cd pw[5];                                        // d^(2^i), d = w^(sc TPF)
-        pw[0] = lookup(sc * TPF);
+        pw[0] = lookup(sct * TPF);
         __syncthreads();
         if (!FAR && more) load_group(g + gridDim.x, v);
 #pragma unroll
@@ -139,7 +164,9 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
                 bs[t] = w;
             }
             const int k = k0 + TPF * u;
-            st_c<STREAM>(&outp[(int64_t)k * a.S], cmul(smem[c * LDSF + lds_pad<S>(k)], w));
+            const Cd z = cmul(smem[c * LDSF + lds_pad<S>(k)], w);
+            if (XF == XF_PUSH) st_c<STREAM>(a.push_tab[k >> a.push_shift] + (int64_t)(k & a.push_mask) * a.push_row + sc, z);
+            else st_c<STREAM>(&outp[(int64_t)k * a.S], z);
         }
         if (FAR) {
 #pragma unroll
@@ -212,11 +239,11 @@ static const Cd* tw_table(int64_t n, int64_t count, int64_t stride) {
     return static_cast<const Cd*>(get_cached_table(key, (size_t)count * 16, fill_tw, &c));
 }
 
-template <int LR, int B, bool FAR = false, bool NT = false>
+template <int LR, int B, bool FAR = false, bool NT = false, int XF = XF_PLAIN>
 static int launch_strided(C2cArgs a, hipStream_t st) {
     constexpr int lds = lds_fft_elems<double, LR>() * B * 16 + (FAR ? (16 << LR) : 0);
     static_assert(lds <= 160 * 1024, "strided pass does not fit LDS");
-    auto kern = c2c_strided_pass<LR, B, FAR, NT>;
+    auto kern = c2c_strided_pass<LR, B, FAR, NT, XF>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t ngroups = a.batch * a.A * (a.S / B);
@@ -241,6 +268,7 @@ static int launch_final(C2cArgs a, hipStream_t st) {
 // Nontemporal passes once the data set is far beyond the caches (>= SA_C2C_NT_MIB MiB per buffer, default 1024;
 // 0 = never): below that the next pass still finds part of this one's output in L2 / MALL.
 static bool c2c_stream_nt(const C2cArgs& a) {
+    if (a.nt_hint >= 0) return a.nt_hint != 0;
     static const long mib = getenv("SA_C2C_NT_MIB") ? atol(getenv("SA_C2C_NT_MIB")) : 1024;
     return mib > 0 && a.n * a.batch * 16 >= mib * (1L << 20);
 }
@@ -264,6 +292,26 @@ static int run_strided(int lr, const C2cArgs& a, hipStream_t st) {
         case 8: return launch_strided<8, 8>(a, st);
         case 9: return launch_strided<9, 8>(a, st);
         case 10: return launch_strided<10, 8>(a, st);
+    }
+    set_error("c2c: internal factor 2^%d unsupported", lr);
+    return SA_EUNSUP;
+}
+// Strided passes of the distributed transform: XF_BLK reads the exchange's block layout, XF_PUSH stores into the
+// owners' receive buffers.  Long passes (every workgroup loops over several column groups) take the early-load
+// form, streaming once the rank's slab is far beyond the caches, like the plain passes above.
+template <int XF>
+static int run_strided_x(int lr, const C2cArgs& a, hipStream_t st) {
+    const bool far = a.batch * a.A * (a.S / 8) >= 8 * (int64_t)num_cus();
+    if (far && c2c_stream_nt(a)) {
+        if (lr == 10) return launch_strided<10, 8, true, true, XF>(a, st);
+        if (lr == 9) return launch_strided<9, 8, true, true, XF>(a, st);
+    }
+    switch (lr) {
+        case 6: return launch_strided<6, 8, false, false, XF>(a, st);
+        case 7: return launch_strided<7, 8, false, false, XF>(a, st);
+        case 8: return launch_strided<8, 8, false, false, XF>(a, st);
+        case 9: return launch_strided<9, 8, false, false, XF>(a, st);
+        case 10: return launch_strided<10, 8, false, false, XF>(a, st);
     }
     set_error("c2c: internal factor 2^%d unsupported", lr);
     return SA_EUNSUP;
@@ -324,6 +372,7 @@ int c2c_f64_dev(const double* in, double* out, double* work, int64_t n, int64_t 
     if (batch <= 0) return batch == 0 ? SA_OK : (set_error("batch < 0"), SA_EINVAL);
     const bool inverse = flags & 1;
     C2cArgs a{};
+    a.nt_hint = -1;
     a.n = n; a.batch = batch;
     a.scale = inverse ? 1.0 / (double)n : 1.0;
     a.natural = (flags & 2) ? 0 : 1;
@@ -371,36 +420,86 @@ int c2c_f64_dev(const double* in, double* out, double* work, int64_t n, int64_t 
     return run_final_multi(l3, a, st);
 }
 
-// data[r][c] *= w_n^{(row0 + r) * c}: the inter-GPU twiddle of the distributed four-step (rows = local
-// columns n2 of the global matrix, c = k1).
-__global__ void twiddle_rows_kernel(Cd* __restrict__ data, int64_t rows, int64_t cols, int64_t row0, int64_t n,
-                                    const Cd* __restrict__ tlo, const Cd* __restrict__ thi, int h) {
-    const int64_t total = rows * cols;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / cols, c = i % cols;
-        const int64_t j = (int64_t)(((__int128)(row0 + r) * c) % n);
-        const Cd w = cmul(thi[j >> h], tlo[j & ((1LL << h) - 1)]);
-        data[i] = cmul(data[i], w);
+// ---- building blocks of the distributed four-step (dist_fft.hip) ---------------------------------------------------
+// The distributed transform of n = R1 * S points IS the multi-pass transform above with the exchange put between its
+// first pass and the rest: rank r owns columns [r Sp, (r+1) Sp) of the [R1][S] view (Sp = S / P), runs the first
+// strided pass on them (twiddle w_n^{s k1} with the GLOBAL column s), rows k1 travel to their owners, and every owner
+// finishes its R1 / P rows as a batch of independent S-point transforms.
+
+// Pass 1 of rank r: in [R1][Sp] (local columns) -> [R1][Sp] rows k1 (times w_n^{(col0 + s) k1}); with push_tab the
+// rows go straight to their owners: row k -> push_tab[k >> push_shift] + (k & push_mask) * Sp + s.
+int dist_pass1(const double* in, double* out, double* const* push_tab, int push_shift, int64_t n, int l1, int64_t Sp,
+               int64_t col0, int nt, hipStream_t st) {
+    C2cArgs a{};
+    a.nt_hint = nt;
+    a.n = (int64_t)Sp << l1; a.batch = 1;               // per-rank extent (addresses); the twiddle tables cover n
+    a.in = reinterpret_cast<const Cd*>(in); a.out = reinterpret_cast<Cd*>(out);
+    a.A = 1; a.S = Sp; a.tw_col0 = col0; a.scale = 1.0;
+    a.twR = tw_table(1LL << l1, 1LL << l1, 1);
+    if (!a.twR) return SA_EHIP;
+    SA_TRY(set_pass_twiddles(a, n));
+    if (push_tab) {
+        a.push_tab = reinterpret_cast<Cd* const*>(push_tab);
+        a.push_shift = push_shift; a.push_mask = ((int64_t)1 << push_shift) - 1; a.push_row = Sp;
+        return run_strided_x<XF_PUSH>(l1, a, st);
     }
+    return run_strided_x<XF_PLAIN>(l1, a, st);
+}
+
+// [P][rows][Sp] -> [rows][S]: only for transforms so short that the owner finishes a row in one LDS pass
+__global__ void unblock_rows_kernel(const Cd* __restrict__ in, Cd* __restrict__ out, int64_t rows, int64_t S, int blk_shift,
+                                    int64_t blk_pitch, int64_t blk_row) {
+    const int64_t total = rows * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / S, s = i % S;
+        out[i] = in[b * blk_row + (s >> blk_shift) * blk_pitch + (s & (((int64_t)1 << blk_shift) - 1))];
+    }
+}
+
+// The owner's part: `rows` transforms of S points whose input sits in the exchange's block layout (element s of row b
+// at in + b Sp + (s / Sp) blk_pitch + s % Sp); out [rows][S] natural order, work [rows][S].
+int dist_phase2(const double* in_blocked, double* work, double* out, int64_t S, int64_t rows, int64_t Sp, int64_t blk_pitch,
+                int nt, hipStream_t st) {
+    int LS = 0, lsp = 0;
+    while ((1LL << LS) < S) ++LS;
+    while ((1LL << lsp) < Sp) ++lsp;
+    if (rows <= 0) return SA_OK;
+    C2cArgs a{};
+    a.nt_hint = nt;
+    a.n = S; a.batch = rows; a.scale = 1.0; a.natural = 1;
+    if (LS <= 12) {
+        const int64_t total = rows * S;
+        const int64_t nb = (total + 255) / 256;
+        hipLaunchKernelGGL(unblock_rows_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, st,
+                           reinterpret_cast<const Cd*>(in_blocked), reinterpret_cast<Cd*>(work), rows, S, lsp, blk_pitch, Sp);
+        SA_HIP(hipGetLastError());
+        a.in = reinterpret_cast<const Cd*>(work); a.out = reinterpret_cast<Cd*>(out);
+        a.A = 1; a.R1 = 1; a.R2 = 1;
+        a.twR = tw_table(S, S, 1);
+        if (!a.twR) return SA_EHIP;
+        return run_final_single(LS, a, st);
+    }
+    if (LS > 20) { set_error("dist c2c: per-row length 2^%d beyond two passes", LS); return SA_EUNSUP; }
+    const int l1 = (LS + 1) / 2, l2 = LS - l1;
+    const int64_t R1 = 1LL << l1, R2 = 1LL << l2;
+    if (R2 > Sp) { set_error("dist c2c: too many ranks for this length (columns per rank %lld < %lld)", (long long)Sp, (long long)R2); return SA_EUNSUP; }
+    a.in = reinterpret_cast<const Cd*>(in_blocked); a.out = reinterpret_cast<Cd*>(work);
+    a.A = 1; a.S = S / R1;
+    a.blk_shift = lsp; a.blk_mask = Sp - 1; a.blk_pitch = blk_pitch; a.blk_row = Sp;
+    a.twR = tw_table(R1, R1, 1);
+    if (!a.twR) return SA_EHIP;
+    SA_TRY(set_pass_twiddles(a, S));
+    SA_TRY(run_strided_x<XF_BLK>(l1, a, st));
+    a.in = reinterpret_cast<const Cd*>(work); a.out = reinterpret_cast<Cd*>(out);
+    a.A = R1; a.R1 = R1; a.R2 = 1;
+    a.twR = tw_table(R2, R2, 1);
+    if (!a.twR) return SA_EHIP;
+    return run_final_multi(l2, a, st);
 }
 
 }  // namespace sa
 
 extern "C" {
-
-int sa_twiddle_rows_f64_dev(double* data_ri, int64_t rows, int64_t cols, int64_t row0, int64_t n, void* stream) {
-    using namespace sa;
-    SA_TRY(ensure_init());
-    if (!data_ri || rows < 0 || cols < 0 || n < 2 || (n & (n - 1))) { set_error("sa_twiddle_rows_f64_dev: bad arguments"); return SA_EINVAL; }
-    if (rows == 0 || cols == 0) return SA_OK;
-    hipStream_t st = stream ? (hipStream_t)stream : thread_stream();
-    C2cArgs a{};
-    SA_TRY(set_pass_twiddles(a, n));
-    hipLaunchKernelGGL(twiddle_rows_kernel, dim3(num_cus() * 8), dim3(256), 0, st, reinterpret_cast<Cd*>(data_ri), rows, cols, row0, n,
-                       a.tlo, a.thi, a.h);
-    SA_HIP(hipGetLastError());
-    return SA_OK;
-}
 
 int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_t n, int64_t batch, int32_t flags,
                        void* stream) {

@@ -7,17 +7,17 @@ Two sharding patterns, as SURVEY §8(e):
    (peak_bin, peak_mag) records.  `shard_range` is the single source of truth for the partition;
    `stft_shard` adds the sample span (with its nfft - hop halo) a rank's STFT frames need.
 
-2. One huge complex FFT (BASELINE config 5) = distributed four-step with ONE all-to-all:
-       view x as [N1][N2] row-major (n = n1*N2 + n2); rank r owns columns n2 in [r*N2/P, (r+1)*N2/P)
-       (a) local length-N1 FFTs down the owned columns            (fp64 c2c engine)
-       (b) twiddle  w_N^{n2*k1}                                    (sa_twiddle_rows_f64_dev)
-       (c) all-to-all: rank q receives k1 in [q*N1/P, (q+1)*N1/P) for every n2   (RCCL)
-       (d) local length-N2 FFTs along n2                           (fp64 c2c engine)
-   Result: rank q owns rows k1 of X[k1 + N1*k2] ("transposed" order, [N1/P][N2]).  Natural-order
-   slabs on either side cost one more all-to-all each (`slab_to_columns`, `rows_to_slab`).
+2. One huge complex FFT (BASELINE config 5) = distributed four-step with ONE all-to-all, run entirely inside
+   libspecengine (csrc/dist_fft.hip; `DistPlan` below is its ctypes face — no torch on this path):
+       view x as [R1][S] row-major; rank r owns columns [r*S/P, (r+1)*S/P)
+       (a) first strided pass down the owned columns, twiddle w_n^{s*k1} fused          (fft_c2c.hip)
+       (b) all-to-all: row k1 goes to rank k1 // (R1/P) — hipMemcpyAsync / copy kernel over peer-mapped memory, or fused
+           into (a)'s store epilogue; delivered in chunks so owners start on arrived rows
+       (c) owners finish their rows as S-point transforms, reading the exchange's block layout in place
+   Result: rank q owns rows k1 of X[k1 + R1*k'] ("transposed" order, [R1/P][S]).  Natural-order slabs on either side
+   cost one more all-to-all each (flags).
 
-torch is plumbing here (device tensors + the collective); every FFT / twiddle runs in libspecengine.
-The local engine is injectable so the orchestration is unit-tested on CPU with gloo (tests/).
+torch appears only in `gather_peaks` (result gather of the frame-sharded paths, 8 bytes per frame).
 """
 import numpy as np
 
@@ -85,132 +85,133 @@ def stft_pcm16_sharded(pcm, nfft=8192, hop=2048, window="blackman", win_param=0.
     return f_lo, f_hi, mag, pb, pm
 
 
-# ---- local engines ---------------------------------------------------------------------------------
-class HipEngine:
-    """Local FFT / twiddle on the GPU through the C ABI, operating on torch device tensors in place."""
+# ---- BASELINE config 5: one huge FFT over P ranks, entirely inside libspecengine (csrc/dist_fft.hip) -------------
+class DistPlan:
+    """A distributed fp64 complex FFT of n = 2^L points over `n_ranks` ranks driven by THIS process
+    (sa_dist_plan_*: first pass -> one all-to-all -> owners' passes, all hand-written HIP; torch is not involved).
 
-    def __init__(self):
-        from . import _lib
-        self._lib = _lib
-        self.lib = _lib.load()
-        self._work = None
+    devices: rank -> HIP device (None: rank i on device i % device_count).  Several ranks may share a device
+    ("virtual ranks"), which is how the whole path is tested on a one-GPU machine.
+    exchange: "auto" | "dma" | "kernel" | "fused";  chunks: row chunks the exchange is delivered in (DMA / kernel).
+    natural_in / natural_out: contiguous slabs x[r n/P ...] / X[q n/P ...] instead of column / row blocks, one more
+    all-to-all each.  Layouts: see include/specengine.h (sa_dist_plan_create) and the helpers below."""
 
-    def _ptr(self, t):
+    def __init__(self, n, n_ranks, devices=None, exchange="auto", chunks=0, natural_in=False, natural_out=False):
         import ctypes as C
-        return C.c_void_p(t.data_ptr())
+        from . import _lib
+        self._lib, self._C = _lib, C
+        self.lib = _lib.load()
+        flags = (_lib.DIST_NATURAL_IN if natural_in else 0) | (_lib.DIST_NATURAL_OUT if natural_out else 0)
+        flags |= _lib.DIST_XCHG_NAMES[exchange] << 4 | int(chunks) << 8
+        devs = None
+        if devices is not None:
+            if len(devices) != n_ranks:
+                raise ValueError("devices must list one HIP device per rank")
+            devs = (C.c_int32 * n_ranks)(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        _lib.check(self.lib.sa_dist_plan_create(C.byref(self._h), int(n), int(n_ranks), devs, flags))
+        self.n, self.n_ranks, self.natural_in, self.natural_out = int(n), int(n_ranks), bool(natural_in), bool(natural_out)
+        self.info = [self._info(r) for r in range(n_ranks)]
+        i0 = self.info[0]
+        self.R1, self.S, self.cols_per_rank, self.rows_per_rank = i0.R1, i0.S, i0.cols_per_rank, i0.rows_per_rank
+        self.exchange = {v: k for k, v in _lib.DIST_XCHG_NAMES.items()}[i0.exchange_mode]
+        self.n_chunks = i0.n_chunks
 
-    def fft_rows(self, a):
-        """a: complex128 [batch, n] contiguous device tensor; forward FFT of every row.  Returns the tensor
-        holding the result: `a` itself for n <= 4096 (in place), otherwise a second buffer (`a` becomes scratch;
-        no copy back)."""
-        import torch
-        batch, n = a.shape
-        stream = self._lib.torch_stream()
-        work = None
-        if n > 4096:
-            if self._work is None or self._work.numel() < a.numel():
-                self._work = torch.empty(a.numel(), dtype=torch.complex128, device=a.device)
-            work = self._work
-        out = torch.empty_like(a) if n > 4096 else a
-        self._lib.check(self.lib.sa_fft_c2c_f64_dev(self._ptr(a), self._ptr(out), self._ptr(work) if work is not None else None,
-                                                    n, batch, 0, stream))
+    def _info(self, rank):
+        inf = self._lib.DistInfo()
+        self._lib.check(self.lib.sa_dist_plan_info(self._h, rank, self._C.byref(inf)))
+        return inf
+
+    def _on(self, rank):
+        self._lib.check(self.lib.sa_set_device(self.info[rank].device))
+
+    def upload(self, rank, slab):
+        """Host complex128 array (slab_elems values, any shape) -> rank's input slab."""
+        slab = np.ascontiguousarray(slab, dtype=np.complex128)
+        if slab.size != self.info[rank].slab_elems:
+            raise ValueError(f"rank {rank}: slab has {slab.size} values, expected {self.info[rank].slab_elems}")
+        self._on(rank)
+        self._lib.check(self.lib.sa_memcpy_h2d(self.info[rank].in_, self._lib.ptr(slab), slab.nbytes))
+
+    def download(self, rank):
+        """Rank's output slab as a host complex128 vector of slab_elems values."""
+        out = np.empty(self.info[rank].slab_elems, dtype=np.complex128)
+        self._on(rank)
+        self._lib.check(self.lib.sa_memcpy_d2h(self._lib.ptr(out), self.info[rank].out, out.nbytes))
         return out
 
-    def twiddle_rows(self, a, row0, n):
-        import torch
-        rows, cols = a.shape
-        stream = self._lib.torch_stream()
-        self._lib.check(self.lib.sa_twiddle_rows_f64_dev(self._ptr(a), rows, cols, int(row0), int(n), stream))
-        return a
+    def scatter(self, x):
+        """Natural-order host vector -> every rank's input slab in the plan's input layout."""
+        x = np.asarray(x, dtype=np.complex128).reshape(-1)
+        P = self.n_ranks
+        for r in range(P):
+            self.upload(r, x[r * (self.n // P):(r + 1) * (self.n // P)] if self.natural_in else columns_of(x, self.R1, self.S, r, P))
+
+    def gather(self):
+        """Every rank's output slab -> natural-order host vector X."""
+        parts = [self.download(r) for r in range(self.n_ranks)]
+        if self.natural_out:
+            return np.concatenate(parts)
+        return natural_from_rows([p.reshape(self.rows_per_rank, self.S) for p in parts], self.R1, self.S)
+
+    def fill(self, kind, param=0, seed=0):
+        """Analytic input generated on the devices: kind "impulse" (at index param), "tone" (bin param), "noise"."""
+        k = {"impulse": self._lib.DIST_KAT_IMPULSE, "tone": self._lib.DIST_KAT_TONE, "noise": self._lib.DIST_KAT_NOISE}[kind]
+        self._lib.check(self.lib.sa_dist_fill(self._h, k, int(param), int(seed)))
+
+    def check(self, kind, param):
+        """max |X[k] - closed form| over all ranks' output slabs, computed on the devices."""
+        k = {"impulse": self._lib.DIST_KAT_IMPULSE, "tone": self._lib.DIST_KAT_TONE}[kind]
+        err = self._C.c_double(0)
+        self._lib.check(self.lib.sa_dist_check(self._h, k, int(param), self._C.byref(err)))
+        return err.value
+
+    def execute(self):
+        """Run the transform (synchronous).  Returns the sa_dist_stats of the call as a dict."""
+        st = self._lib.DistStats()
+        self._lib.check(self.lib.sa_dist_execute(self._h, self._C.byref(st)))
+        P = self.n_ranks
+        d = {k: getattr(st, k) for k, _ in st._fields_ if k not in ("link_gbps", "reserved")}
+        d["exchange_mode"] = self.exchange
+        d["link_gbps"] = [[st.link_gbps[i][q] for q in range(P)] for i in range(P)]
+        return d
+
+    def close(self):
+        if self._h:
+            self.lib.sa_dist_plan_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-A2A_MAX_BYTES_PER_PEER = 1 << 30      # keep every per-peer message below 2^31 bytes
-
-
-def _all_to_all(out, inp, group):
-    """out[p] <- rank p's inp[my rank]; out/inp: complex [P][rows][cols] contiguous.
-
-    A per-peer block of 4 GiB (2^28 complex128: a 2^28-point transform on one rank, 2^30 on two) came back
-    untouched from a single all_to_all_single call on this stack (32-bit byte count somewhere below torch), so
-    blocks above A2A_MAX_BYTES_PER_PEER go in row slices; a one-rank group is a plain copy."""
-    import torch
-    import torch.distributed as dist
-    P = dist.get_world_size(group)
-    if P == 1:
-        out.copy_(inp)
-        return
-    per_peer = inp[0].numel() * inp.element_size()
-    if per_peer <= A2A_MAX_BYTES_PER_PEER:
-        dist.all_to_all_single(torch.view_as_real(out), torch.view_as_real(inp), group=group)
-        return
-    rows = inp.shape[1]
-    step = max(1, rows * A2A_MAX_BYTES_PER_PEER // per_peer)
-    for r0 in range(0, rows, step):
-        si = inp[:, r0:r0 + step].contiguous()
-        so = torch.empty_like(si)
-        dist.all_to_all_single(torch.view_as_real(so), torch.view_as_real(si), group=group)
-        out[:, r0:r0 + step].copy_(so)
-
-
-def dist_transpose(a, group=None):
-    """Distributed transpose of a [R][C] matrix held as row blocks: local [R/P][C] -> local [C/P][R]."""
-    import torch
-    import torch.distributed as dist
-    P = dist.get_world_size(group)
-    rl, C = a.shape
-    cl = C // P
-    send = a.reshape(rl, P, cl).permute(1, 0, 2).contiguous()       # [P][rl][cl]: block q goes to rank q
-    recv = torch.empty_like(send)
-    _all_to_all(recv, send, group)                                   # recv[p] = rows of rank p, my columns
-    return recv.permute(2, 0, 1).reshape(cl, P * rl).contiguous()    # [cl][R]
-
-
-def fft_four_step(cols_local, n1, n2, engine, group=None, stats=None):
-    """Distributed forward FFT of length N = n1*n2.
-
-    cols_local: complex128 [n1][n2/P] — this rank's columns of the row-major [n1][n2] view of x.
-    Returns     complex128 [n1/P][n2] — rows k1 of X[k1 + n1*k2] (k1 = rank*n1/P + row).
-    `stats` (dict) receives the all-to-all time in seconds and bytes sent per peer when given."""
-    import time
-    import torch
-    import torch.distributed as dist
-    P = dist.get_world_size(group)
-    r = dist.get_rank(group)
-    c = n2 // P
-    assert cols_local.shape == (n1, c) and n1 % P == 0 and n2 % P == 0
-    N = n1 * n2
-    a = cols_local.t().contiguous()                                  # [c][n1]: local columns as rows
-    a = engine.fft_rows(a)                                           # (a) FFT over n1 -> k1
-    engine.twiddle_rows(a, r * c, N)                                 # (b) w_N^{n2 k1}
-    k1l = n1 // P
-    send = a.reshape(c, P, k1l).permute(1, 0, 2).contiguous()        # [P][c][k1l]
-    recv = torch.empty_like(send)
-    if stats is not None and a.is_cuda:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    _all_to_all(recv, send, group)                                   # (c) the one exchange
-    if stats is not None:
-        if a.is_cuda:
-            torch.cuda.synchronize()
-        stats["all_to_all_s"] = time.perf_counter() - t0
-        stats["bytes_per_peer"] = c * k1l * 16
-    b = recv.reshape(P * c, k1l).t().contiguous()                    # [k1l][n2]
-    return engine.fft_rows(b)                                        # (d) FFT over n2 -> k2
-
-
-def slab_to_columns(slab_local, n1, n2, group=None):
-    """Natural-order input slab (rows n1 of the [n1][n2] view, local [n1/P][n2]) -> column blocks [n1][n2/P]."""
-    return dist_transpose(slab_local, group).t().contiguous()
-
-
-def rows_to_slab(rows_local, n1, n2, group=None):
-    """Output rows [n1/P][n2] of X[k1 + n1*k2] -> natural-order slab of k (local [n2/P][n1], k = k1 + n1*k2)."""
-    return dist_transpose(rows_local, group)
+def fft_dist(x, n_ranks=0, exchange="auto", chunks=0):
+    """np.fft.fft(x) for a power-of-two complex128 vector through the distributed four-step (host arrays in natural order
+    on both sides: sa_fft_c2c_f64_dist).  Returns (X, stats dict).  n_ranks = 0: one rank per visible device."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    x = np.ascontiguousarray(x, dtype=np.complex128).reshape(-1)
+    out = np.empty_like(x)
+    st = _lib.DistStats()
+    flags = _lib.DIST_XCHG_NAMES[exchange] << 4 | int(chunks) << 8
+    _lib.check(lib.sa_fft_c2c_f64_dist(_lib.ptr(x), _lib.ptr(out), x.size, int(n_ranks), flags, C.byref(st)))
+    return out, {k: getattr(st, k) for k, _ in st._fields_ if k not in ("link_gbps", "reserved")}
 
 
 # ---- host helpers for tests / small problems ---------------------------------------------------------
 def columns_of(x, n1, n2, rank, world):
-    """numpy: the [n1][n2/P] column block of rank `rank` for a natural-order vector x."""
+    """numpy: the [n1][n2/P] column block of rank `rank` for a natural-order vector x (DistPlan's default input layout
+    with n1 = plan.R1, n2 = plan.S)."""
     c = n2 // world
     return np.ascontiguousarray(np.asarray(x).reshape(n1, n2)[:, rank * c:(rank + 1) * c])
 

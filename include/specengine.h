@@ -124,9 +124,69 @@ int sa_fill_tone_noise_f32_dev(float* x, int64_t batch, int32_t n, double fs, ui
 int sa_fft_c2c_f64(const double* in_ri, double* out_ri, int64_t n, int64_t batch, int32_t flags);
 int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_t n, int64_t batch,
                        int32_t flags, void* stream);
-/* Inter-GPU twiddle of the distributed four-step (fft_amd/dist.py): data[r][c] *= w_n^{(row0 + r) c},
- * data = rows x cols complex fp64 (device), n a power of two; exact index arithmetic, two-level table. */
-int sa_twiddle_rows_f64_dev(double* data_ri, int64_t rows, int64_t cols, int64_t row0, int64_t n, void* stream);
+
+/* ---- BASELINE config 5 across GPUs: ONE fp64 complex FFT of n = 2^L points as a distributed four-step --------------
+ * No counterpart in the reference (single process, CPU: SURVEY §0); the arithmetic is scipy.fft.fft's (main.py:475).
+ * ONE host process drives P ranks (P a power of two <= SA_DIST_MAX_RANKS).  A rank is a device plus its own streams
+ * and buffers; `devices` maps rank -> HIP device (NULL: rank i on device i % sa_device_count()).  Several ranks may
+ * share a device ("virtual ranks": the whole path runs on a one-GPU machine), ranks on different devices exchange
+ * through peer-mapped memory over xGMI.
+ *
+ *   n = R1 * S, x viewed as [R1][S] row-major; cols_per_rank = S / P, rows_per_rank = R1 / P (sa_dist_plan_info)
+ *   default input   rank r holds columns [r S/P, (r+1) S/P) of that view:  in[i * S/P + c] = x[i * S + r S/P + c]
+ *   default output  rank q holds rows k1 in [q R1/P, (q+1) R1/P):         out[j * S + k'] = X[(q R1/P + j) + R1 k']
+ *   -> ONE all-to-all, n/P^2 points per ordered pair of ranks.
+ *   SA_DIST_NATURAL_IN / _OUT: contiguous slabs x[r n/P ...] / X[q n/P ...] instead, one more all-to-all each.
+ * Exchange: SA_DIST_XCHG(mode) — DMA = one hipMemcpyAsync per (source, owner, chunk); KERNEL = the same copies by a
+ * copy kernel storing through the peer mapping; FUSED = the first pass' store epilogue writes straight into the owners'
+ * receive buffers (no send buffer, no copy pass); AUTO = FUSED when every rank shares one device, else DMA.
+ * DMA / KERNEL deliver in SA_DIST_CHUNKS(j) row chunks (default 4) and an owner transforms a chunk while the rest is
+ * still on the wire.  sa_dist_execute is synchronous (returns when every rank is done) and fills `stats` if given. */
+#define SA_DIST_MAX_RANKS    16
+#define SA_DIST_NATURAL_IN   1
+#define SA_DIST_NATURAL_OUT  2
+#define SA_DIST_XCHG_AUTO    0
+#define SA_DIST_XCHG_DMA     1
+#define SA_DIST_XCHG_KERNEL  2
+#define SA_DIST_XCHG_FUSED   3
+#define SA_DIST_XCHG(mode)   ((mode) << 4)
+#define SA_DIST_CHUNKS(j)    ((j) << 8)
+typedef struct sa_dist_plan sa_dist_plan;
+typedef struct sa_dist_info {
+    int64_t n, R1, S, cols_per_rank, rows_per_rank, slab_elems /* complex values per rank = n / P */;
+    int32_t n_ranks, n_devices, device, exchange_mode, n_chunks, reserved;
+    double* in;                 /* this rank's input slab  (device memory, slab_elems interleaved re/im pairs)  */
+    double* out;                /* this rank's output slab (device memory)                                      */
+} sa_dist_info;
+typedef struct sa_dist_stats {
+    int64_t n, bytes_per_peer;  /* bytes each rank sends to each other rank in the main exchange: 16 n / P^2    */
+    int32_t n_ranks, n_devices, exchange_mode, n_chunks, exchanges /* all-to-alls run: 1, 2 or 3 */, reserved;
+    double  total_ms;           /* host wall clock of the call                                                  */
+    double  device_ms;          /* longest first-event -> last-event span of any rank                           */
+    double  pass1_ms, phase2_ms;/* longest first pass / longest owner phase of any rank (HIP events)            */
+    double  exchange_ms;        /* longest (first copy start -> last copy end) of any inter-rank pair; 0 if FUSED */
+    double  link_gbps_min, link_gbps_mean, link_gbps_max;   /* over ordered pairs p != q                        */
+    double  aggregate_gbps;     /* all inter-rank bytes / exchange_ms (FUSED: / pass1_ms)                       */
+    double  link_gbps[SA_DIST_MAX_RANKS][SA_DIST_MAX_RANKS]; /* [source][owner]: bytes_per_peer / that pair's copy time
+                                   (FUSED: / the source's pass-1 time, a lower bound); diagonal = local copies */
+} sa_dist_stats;
+int sa_dist_plan_create(sa_dist_plan** plan, int64_t n, int32_t n_ranks, const int32_t* devices, int32_t flags);
+int sa_dist_plan_info(const sa_dist_plan* plan, int32_t rank, sa_dist_info* info);
+int sa_dist_execute(sa_dist_plan* plan, sa_dist_stats* stats /* may be NULL */);
+int sa_dist_plan_destroy(sa_dist_plan* plan);
+/* Analytic inputs written straight into the ranks' input slabs, and the matching closed-form check of the output slabs
+ * (SURVEY §8(d) C5 known answers, for sizes no host buffer should hold): IMPULSE at index `param` -> X[k] =
+ * e^{-2 pi i k param / n}; TONE e^{+2 pi i param j / n} -> X[param] = n, 0 elsewhere; NOISE = N(0,1) pairs keyed by
+ * (seed, j) (no closed form: compare with another transform of the same data).  *max_abs_err = max |X[k] - expected|. */
+#define SA_DIST_KAT_IMPULSE  0
+#define SA_DIST_KAT_TONE     1
+#define SA_DIST_KAT_NOISE    2
+int sa_dist_fill(sa_dist_plan* plan, int32_t kind, int64_t param, uint64_t seed);
+int sa_dist_check(sa_dist_plan* plan, int32_t kind, int64_t param, double* max_abs_err);
+/* Host arrays in natural order on both sides (the library shards, exchanges three times and gathers): the form
+ * SURVEY §8(b) lists.  n_ranks = 0: one rank per visible device.  PCIe-bound for large n; benchmarks use the plan. */
+int sa_fft_c2c_f64_dist(const double* in_ri, double* out_ri, int64_t n, int32_t n_ranks, int32_t flags,
+                        sa_dist_stats* stats /* may be NULL */);
 
 /* ---- a6/a8/a9 for ARBITRARY frame length (the GUI drop-in path) ----------------------------------
  * |fft(y*w)| of real fp64 frames of any length n >= 1: bins 0..n/2, plus the dominant peak.
