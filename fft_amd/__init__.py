@@ -8,6 +8,6 @@ the on-disk formats either side of the path (FNIRSI dump, JSON/CSV export, RIFF 
 """
 from . import _lib  # noqa: F401
 from . import formats  # noqa: F401
-from .batch import fft_c2c, fft_mag, rfft_peak, stft_pcm16, window_id  # noqa: F401
+from .batch import fft_c2c, fft_mag, rfft_peak, set_shard_devices, stft_pcm16, window_id  # noqa: F401
 
-__all__ = ["rfft_peak", "fft_c2c", "fft_mag", "stft_pcm16", "window_id"]
+__all__ = ["rfft_peak", "fft_c2c", "fft_mag", "stft_pcm16", "window_id", "set_shard_devices"]

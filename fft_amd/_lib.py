@@ -36,6 +36,8 @@ PROTOTYPES = {
     "sa_memcpy_d2h": (C.c_int, [_vp, _vp, _u64]),
     "sa_sync": (C.c_int, []),
     "sa_thread_state_count": (C.c_int, []),
+    "sa_shard_devices": (C.c_int, [_vp, _i32]),
+    "sa_shard_count": (C.c_int, []),
     "sa_rfft_peak_f32": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "sa_rfft_peak_f64": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "sa_rfft_peak_f32_dev": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp]),

@@ -17,6 +17,23 @@ def window_id(window):
     return _lib.WINDOW_IDS[key]
 
 
+def set_shard_devices(devices):
+    """Fan the host-array batch calls (rfft_peak, stft_pcm16, specengine.synth_analyze / analyze_frames) out over these
+    HIP devices from THIS process: one host thread + stream + pinned staging per entry (sa_shard_devices).  `devices`:
+    a list of device ids (a device may repeat: several shards on one GPU), an int G (shards 0..G-1 round-robin over the
+    visible devices), or None / 0 / 1 to switch the fan-out off.  Results are bit-identical to the unsharded calls."""
+    import ctypes as C
+    lib = _lib.load()
+    if devices is None:
+        devices = 0
+    if isinstance(devices, (int, np.integer)):
+        _lib.check(lib.sa_shard_devices(None, int(devices)))
+    else:
+        arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        _lib.check(lib.sa_shard_devices(arr, len(devices)))
+    return int(lib.sa_shard_count())
+
+
 def rfft_peak(x, window="hann", win_param=0.0, write_mag=True, db=False, exclude_dc_nyq=False):
     """x: [batch, n] (or [n]) float32/float64 host array.
 

@@ -174,17 +174,29 @@ static int analyze_frames_host(const T* x, int64_t batch, int32_t n, int32_t win
     return rc;
 }
 
+// records fan out as contiguous blocks over the shard devices (sa_shard_devices); every output is optional
+template <typename T>
+static int analyze_frames_sharded(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs, double side_hz,
+                                  sa_time_stats* ts, sa_spec_metrics* sm, int32_t* peak_bin, T* peak_mag) {
+    if (shard_count() < 2 || batch < 2 || !x || n < 1)
+        return analyze_frames_host<T>(x, batch, n, window, win_param, fs, side_hz, ts, sm, peak_bin, peak_mag);
+    return run_sharded(batch, [&](int64_t lo, int64_t hi) {
+        return analyze_frames_host<T>(x + lo * n, hi - lo, n, window, win_param, fs, side_hz, ts ? ts + lo : nullptr, sm ? sm + lo : nullptr,
+                                      peak_bin ? peak_bin + lo : nullptr, peak_mag ? peak_mag + lo : nullptr);
+    });
+}
+
 }  // namespace sa
 
 extern "C" {
 
 int sa_analyze_frames_f32(const float* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs,
                           double side_hz, sa_time_stats* ts, sa_spec_metrics* sm, int32_t* peak_bin, float* peak_mag) {
-    return sa::analyze_frames_host<float>(x, batch, n, window, win_param, fs, side_hz, ts, sm, peak_bin, peak_mag);
+    return sa::analyze_frames_sharded<float>(x, batch, n, window, win_param, fs, side_hz, ts, sm, peak_bin, peak_mag);
 }
 int sa_analyze_frames_f64(const double* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs,
                           double side_hz, sa_time_stats* ts, sa_spec_metrics* sm, int32_t* peak_bin, double* peak_mag) {
-    return sa::analyze_frames_host<double>(x, batch, n, window, win_param, fs, side_hz, ts, sm, peak_bin, peak_mag);
+    return sa::analyze_frames_sharded<double>(x, batch, n, window, win_param, fs, side_hz, ts, sm, peak_bin, peak_mag);
 }
 int sa_analyze_frames_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs,
                               double side_hz, float* mag_work, sa_time_stats* ts, sa_spec_metrics* sm,

@@ -391,6 +391,20 @@ int rfft_peak_host(const T* x, int64_t batch, int32_t n, int32_t window, double 
     return rc;
 }
 
+// With shard devices configured (sa_shard_devices) the frames fan out as contiguous blocks, one per shard thread; each
+// block runs the host path above on its own device and writes its slice of the caller's outputs.
+template <typename T>
+static int rfft_peak_host_sharded(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
+                                  T* mag, int32_t* peak_bin, T* peak_mag) {
+    if (shard_count() < 2 || batch < 2 || n < 1 || !x || !peak_bin || !peak_mag)      // argument errors: the plain path reports them
+        return rfft_peak_host<T>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag);
+    const int64_t nb = n / 2 + 1;
+    return run_sharded(batch, [&](int64_t lo, int64_t hi) {
+        return rfft_peak_host<T>(x + lo * n, hi - lo, n, window, win_param, flags, mag ? mag + lo * nb : nullptr, peak_bin + lo,
+                                 peak_mag + lo);
+    });
+}
+
 // ---- synthetic C2 frames: Philox4x32-10 keyed by seed, counter = (frame, sample group) ---------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t* out) {
@@ -462,11 +476,11 @@ int sa_rfft_peak_f64_dev(const double* x, int64_t batch, int32_t n, int32_t wind
 }
 int sa_rfft_peak_f32(const float* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
                      float* mag, int32_t* peak_bin, float* peak_mag) {
-    return sa::rfft_peak_host<float>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag);
+    return sa::rfft_peak_host_sharded<float>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag);
 }
 int sa_rfft_peak_f64(const double* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
                      double* mag, int32_t* peak_bin, double* peak_mag) {
-    return sa::rfft_peak_host<double>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag);
+    return sa::rfft_peak_host_sharded<double>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag);
 }
 
 int sa_time_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param,

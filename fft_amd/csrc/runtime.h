@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -88,6 +89,10 @@ int64_t grid_cap(int per_cu, const char* family);
 int rfft4096_metrics_dev(const float* x, int64_t batch, int32_t window, double win_param, int32_t flags, float* mag,
                          int32_t* peak_bin, float* peak_mag, sa_time_stats* ts, sa_spec_metrics* sm, double freq_step,
                          double side_hz, hipStream_t st);       // rfft_batch.hip: fused 4096-point fp32 kernel
+// shard.hip: single-process multi-GPU fan-out of the host-pointer entry points
+int shard_count();                 // shard workers configured with sa_shard_devices (0 = off)
+int run_sharded(int64_t total, const std::function<int(int64_t lo, int64_t hi)>& fn);   // fn runs on every shard's thread
+void shard_shutdown();
 void free_thread_caches();         // sa_shutdown: releases the cached blocks of every thread
 
 }  // namespace sa

@@ -395,6 +395,7 @@ int sa_init(int device) {
 }
 
 void sa_shutdown(void) {
+    sa::shard_shutdown();
     hipDeviceSynchronize();
     sa::free_thread_caches();
     sa::free_all_plans();

@@ -335,20 +335,20 @@ int sa_stft_pcm16_dev(const int16_t* interleaved, int64_t n_samples, int32_t cha
                               scratch, st);
 }
 
-int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop, int32_t window,
-                  double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag) {
+}  // extern "C"
+
+// Frames [f_lo, f_hi) of the recording on the calling thread's device; outputs land at their place among all
+// `nframes` frames of each channel.  The samples a frame range needs (its hop-sized steps plus the nfft - hop halo the
+// next range also reads) come from the host source — shards never exchange samples.
+static int stft_host_range(const int16_t* interleaved, int32_t channels, int32_t nfft, int32_t hop, int32_t window, double win_param,
+                           int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, int64_t nframes, int64_t f_lo, int64_t f_hi) {
     using namespace sa;
-    SA_TRY(ensure_init());
-    if (channels < 1 || nfft < 1 || hop < 1) { set_error("stft: bad channels/nfft/hop"); return SA_EINVAL; }
-    const int64_t nframes = sa_stft_num_frames(n_samples, nfft, hop);
-    if (nframes == 0) return SA_OK;
-    if (!interleaved) { set_error("stft: NULL input"); return SA_EINVAL; }
     hipStream_t st = thread_stream();
     const int64_t nb = nfft / 2 + 1;
     // process in segments of frames so the staging buffers stay bounded (<= ~1 GiB of spectra)
     int64_t seg = (int64_t)(1ull << 30) / (nb * 4 * channels);
     if (seg < 1) seg = 1;
-    if (seg > nframes) seg = nframes;
+    if (seg > f_hi - f_lo) seg = f_hi - f_lo;
     const int64_t seg_samples = (seg - 1) * hop + nfft;
     const bool wmag = flags & SA_F_WRITE_MAG;
     // staging from the thread's arena (small calls reuse its cached block; large ones fall back to one allocation each)
@@ -361,8 +361,8 @@ int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channel
     int rc = SA_OK;
     hipError_t e = hipSuccess;
     if (!dpcm || (wmag && !dmag) || !dpm || !dpb || (!(channels == 2 && nfft <= 8192) && !dscr)) rc = SA_ENOMEM;
-    for (int64_t f0 = 0; rc == SA_OK && f0 < nframes; f0 += seg) {
-        const int64_t nf = nframes - f0 < seg ? nframes - f0 : seg;
+    for (int64_t f0 = f_lo; rc == SA_OK && f0 < f_hi; f0 += seg) {
+        const int64_t nf = f_hi - f0 < seg ? f_hi - f0 : seg;
         const int64_t ns = (nf - 1) * hop + nfft;
         e = hipMemcpyAsync(dpcm, interleaved + f0 * hop * channels, (size_t)ns * channels * 2, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { set_error("stft: H2D failed: %s", hipGetErrorString(e)); rc = SA_EHIP; break; }
@@ -376,7 +376,22 @@ int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channel
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("stft: D2H failed: %s", hipGetErrorString(e)); rc = SA_EHIP; }
     }
+    if (rc != SA_OK) (void)hipStreamSynchronize(st);      // nothing may still be using the arena when it is handed back
     return rc;            // every segment ended with a stream synchronise: the arena blocks are idle
 }
 
-}  // extern "C"
+extern "C" int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop, int32_t window,
+                             double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag) {
+    using namespace sa;
+    SA_TRY(ensure_init());
+    if (channels < 1 || nfft < 1 || hop < 1) { set_error("stft: bad channels/nfft/hop"); return SA_EINVAL; }
+    const int64_t nframes = sa_stft_num_frames(n_samples, nfft, hop);
+    if (nframes == 0) return SA_OK;
+    if (!interleaved) { set_error("stft: NULL input"); return SA_EINVAL; }
+    if (!peak_bin || !peak_mag || ((flags & SA_F_WRITE_MAG) && !mag)) { set_error("stft: NULL output buffer"); return SA_EINVAL; }
+    if (shard_count() >= 2 && nframes >= 2)               // frame ranges fan out over the shard devices (sa_shard_devices)
+        return run_sharded(nframes, [&](int64_t lo, int64_t hi) {
+            return stft_host_range(interleaved, channels, nfft, hop, window, win_param, flags, mag, peak_bin, peak_mag, nframes, lo, hi);
+        });
+    return stft_host_range(interleaved, channels, nfft, hop, window, win_param, flags, mag, peak_bin, peak_mag, nframes, 0, nframes);
+}

@@ -328,6 +328,9 @@ int synth_analyze_dev(const sa_gen_params* dparams, int64_t batch, int32_t n_bas
 
 }  // namespace sa
 
+static int synth_analyze_host(const sa_gen_params* params, int64_t batch, int32_t n_base, int32_t upsample, int32_t window,
+                              double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, float* y_out);
+
 extern "C" {
 
 int sa_synth_analyze_dev(const sa_gen_params* params_dev, int64_t batch, int32_t n_base, int32_t upsample, int32_t window,
@@ -340,6 +343,21 @@ int sa_synth_analyze_dev(const sa_gen_params* params_dev, int64_t batch, int32_t
 
 int sa_synth_analyze(const sa_gen_params* params, int64_t batch, int32_t n_base, int32_t upsample, int32_t window,
                      double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, float* y_out) {
+    if (sa::shard_count() >= 2 && batch >= 2 && params && peak_bin && peak_mag && n_base > 0 && upsample > 0) {
+        // parameter records fan out as contiguous blocks over the shard devices (sa_shard_devices)
+        const int64_t n = (int64_t)n_base * upsample, nb = n / 2 + 1;
+        return sa::run_sharded(batch, [&](int64_t lo, int64_t hi) {
+            return synth_analyze_host(params + lo, hi - lo, n_base, upsample, window, win_param, flags, mag ? mag + lo * nb : nullptr,
+                                      peak_bin + lo, peak_mag + lo, y_out ? y_out + lo * n : nullptr);
+        });
+    }
+    return synth_analyze_host(params, batch, n_base, upsample, window, win_param, flags, mag, peak_bin, peak_mag, y_out);
+}
+
+}  // extern "C"
+
+static int synth_analyze_host(const sa_gen_params* params, int64_t batch, int32_t n_base, int32_t upsample, int32_t window,
+                              double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, float* y_out) {
     using namespace sa;
     SA_TRY(ensure_init());
     if (batch < 0) { set_error("batch < 0"); return SA_EINVAL; }
@@ -375,5 +393,3 @@ int sa_synth_analyze(const sa_gen_params* params, int64_t batch, int32_t n_base,
     if (rc != SA_OK) (void)hipStreamSynchronize(st);      // nothing may still be using the arena when it is handed back
     return rc;
 }
-
-}  // extern "C"

@@ -81,6 +81,18 @@ int  sa_sync(void);                       /* synchronise the calling thread's li
  * time, not the number of threads that ever did.  Diagnostic; no reference counterpart. */
 int  sa_thread_state_count(void);
 
+/* Single-process multi-GPU fan-out of the HOST-pointer batch entry points (SURVEY §8(b) "library stages/shards", §8(e)).
+ * The reference runs this path from one process (a ThreadPoolExecutor worker, main.py:448), so a drop-in caller cannot
+ * start a process per GPU: sa_shard_devices names `count` shard devices (NULL: shard i on device i % sa_device_count();
+ * a device may repeat = several shards on one GPU; count 0 or 1 switches the fan-out off) and starts one host thread
+ * per shard, bound to its device with its own stream and pinned staging.  From then on sa_rfft_peak_f32/_f64,
+ * sa_stft_pcm16 (frame ranges, halo re-read from the host source), sa_synth_analyze and sa_analyze_frames_f32/_f64
+ * hand shard s the contiguous block of frames [s B/G, (s+1) B/G) (first B mod G shards one more) and every shard
+ * writes its slice of the caller's outputs: results are bit-identical to the unsharded call, no device-side exchange.
+ * Sharded calls from several threads run one at a time.  *_dev entry points are not affected. */
+int sa_shard_devices(const int32_t* devices, int32_t count);
+int sa_shard_count(void);
+
 /* ---- a6/a8/a9/a11: window -> real FFT -> |Y| (-> dB) -> dominant peak, batched ----------------
  * Replaces, per frame:  Y = fft(y*w); np.abs(Y); np.argmax(...)   (main.py:475, 479, 1029, 1627)
  * computed as an rfft: bins 0..n/2 (the reference's length-n fftshift layout is rebuilt by the
