@@ -4,7 +4,7 @@
 // main.py:105-107, 511), 1500-sample FNIRSI dumps (main.py:1080), any len(y) in _calculate_fft
 // (main.py:959-965).  Routing:
 //   n power of two, 16..16384   -> fused rfft kernel (rfft_batch.hip);
-//   n power of two, > 16384     -> fp64 c2c engine on (y*w, 0);
+//   n power of two, > 16384     -> multi-pass real FFT (rfft_large.hip: n/2-point c2c + Hermitian unpack);
 //   any other n >= 1            -> Bluestein chirp-z on the c2c engine:
 //        Y[k] = c[k] * IFFT_M( FFT_M(y w c) * FFT_M(b) )[k],  c[k] = exp(-i pi k^2/n),  b = conj chirp,
 //        M = next power of two >= 2n-1; k^2 mod 2n is taken in integers so the chirp is exact to fp64.
@@ -171,7 +171,7 @@ int fft_mag_any_dev(const double* dx, int64_t cnt, int64_t n, int window, double
                            int32_t* dpb, double* dpm, hipStream_t st) {
     const int64_t nb = n / 2 + 1;
     const int l2 = ilog2e(n);
-    if (l2 >= 4 && l2 <= 14)
+    if (l2 >= 4 && l2 <= 29)                               // > 2^14: the multi-pass real-FFT path (rfft_large.hip)
         return rfft_peak_dev<double>(dx, cnt, (int32_t)n, window, win_param, flags, dmag, dpb, dpm, st);
     const RfftPlan* wp = nullptr;
     const double* dwin = nullptr;

@@ -56,6 +56,60 @@ def test_rfft_f64_all_sizes(n, win):
     np.testing.assert_allclose(pm, pmref, rtol=1e-12)
 
 
+@pytest.mark.parametrize("dtype,log2n,batch", [(np.float32, 16, 5), (np.float32, 17, 3), (np.float32, 20, 2), (np.float32, 22, 1),
+                                               (np.float64, 15, 5), (np.float64, 18, 2), (np.float64, 21, 1)])
+@pytest.mark.parametrize("win", ["none", "hann", "gaussian"])
+def test_rfft_long_frames_multi_pass(dtype, log2n, batch, win):
+    """Frames longer than one LDS-resident pass (the late forks reach 1 000 000 points, sab10.py:43, 644): n/2-point
+    complex transform on the multi-pass engine + Hermitian unpack (rfft_large.hip).  Same bars as the short frames:
+    fp32 1e-5 log2 N relative L2 (the path computes in fp64, so it sits at fp32 output rounding), fp64 1e-12."""
+    import fft_amd
+    n = 1 << log2n
+    rng = np.random.default_rng(log2n * 3 + len(win))
+    t = np.arange(n)
+    f0 = rng.uniform(1, n / 2 - 1, size=(batch, 1))
+    x = (np.sin(2 * np.pi * f0 * t / n + rng.uniform(0, 6, (batch, 1))) + 0.1 * rng.standard_normal((batch, n))).astype(dtype)
+    mag, pb, pm = fft_amd.rfft_peak(x, win)
+    mref, pbref, pmref = O.rfft_mag_peak(x, win)
+    assert mag.dtype == dtype and mag.shape == (batch, n // 2 + 1)
+    if dtype == np.float32:
+        assert rel_l2(mag, mref).max() < 1e-5 * log2n
+        assert rel_l2(mag, mref).max() < 2e-7                 # in fact: fp64 arithmetic, fp32 rounding of the outputs
+        check_peaks(pb, pm, mref, pbref)
+        np.testing.assert_allclose(pm, pmref, rtol=1e-6)
+    else:
+        assert (np.abs(mag - mref).max(axis=1) / mref.max(axis=1)).max() < 1e-12
+        np.testing.assert_array_equal(pb, pbref)
+        np.testing.assert_allclose(pm, pmref, rtol=1e-12)
+    # kernel peak == argmax of its own spectrum (lowest bin on ties), and the flags: dB, peak only, DC/Nyquist excluded
+    np.testing.assert_array_equal(pb, np.argmax(mag, axis=1))
+    if win == "hann":
+        magdb, pb2, pm2 = fft_amd.rfft_peak(x, win, db=True, exclude_dc_nyq=True)
+        mrefdb, pbref2, _ = O.rfft_mag_peak(x, win, db=True, exclude_dc_nyq=True)
+        assert np.abs(magdb - mrefdb)[:, 1:-1].max() < (1e-3 if dtype == np.float32 else 1e-9)
+        np.testing.assert_array_equal(pb2, pb)
+        none_, pb3, pm3 = fft_amd.rfft_peak(x, win, write_mag=False)
+        assert none_ is None
+        np.testing.assert_array_equal(pb3, pb); np.testing.assert_array_equal(pm3, pm)
+
+
+def test_rfft_long_frame_dc_and_nyquist_and_anylen_route():
+    """DC-only and alternating +-1 frames put the peak on the two self-paired bins; sa_fft_mag_f64 routes a 2^16-point
+    frame through the same path."""
+    import fft_amd
+    n = 1 << 16
+    x = np.ones((2, n)); x[1] = np.where(np.arange(n) % 2 == 0, 1.0, -1.0)
+    mag, pb, pm = fft_amd.rfft_peak(x, "none")
+    assert list(pb) == [0, n // 2] and np.allclose(pm, n)
+    _, pbx, _ = fft_amd.rfft_peak(x, "none", exclude_dc_nyq=True)
+    assert pbx[0] not in (0, n // 2) and pbx[1] not in (0, n // 2)
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal(n)
+    m2, pb2, pm2 = fft_amd.fft_mag(y, "blackman")
+    mref, pbref, pmref = O.rfft_mag_peak(y[None], "blackman")
+    assert np.abs(m2 - mref[0]).max() / mref.max() < 1e-12 and pb2 == pbref[0]
+
+
 def test_config1_hamming_peak(golden_dir):
     """BASELINE config 1: 10 kHz sine @ 100 kHz, N=4096, Hamming -> rfft bin 410, |Y| = 972.569..."""
     import fft_amd
