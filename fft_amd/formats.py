@@ -123,6 +123,28 @@ def export_data(last_data, path):
             w.writerows(zip(*last_data.values()))
 
 
+V15_HEADER_SIZE, V15_DATA_SIZE = 64, 3000                              # versão15.py:29-30
+
+
+def read_wav_v15(path_or_bytes):
+    """The earlier fork's dump layout (versão15.py:604-640): 64-byte header with the sample rate as a little-endian
+    uint32 at bytes 24..27, then up to 1500 int16-LE samples; returns (fs, y) with y = int16.astype(float32) / 32768
+    — float32, as the reference casts it (:637).  Same error as the reference for files shorter than the header."""
+    if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
+        b = bytes(path_or_bytes)
+    else:
+        with open(path_or_bytes, "rb") as fh:
+            b = fh.read()
+    if len(b) < V15_HEADER_SIZE:
+        raise ValueError("Arquivo muito pequeno para ser um WAV do Fnirsi 1014D")
+    fs_bytes = b[24:28]
+    fs = struct.unpack("<I", fs_bytes)[0] if len(fs_bytes) == 4 else 1000
+    raw = b[V15_HEADER_SIZE:V15_HEADER_SIZE + V15_DATA_SIZE]
+    if len(raw) % 2:
+        raw = raw[:-1]
+    return fs, np.frombuffer(raw, dtype="<i2").astype(np.float32) / np.float32(32768.0)
+
+
 def read_wav_pcm16(path_or_bytes):
     """RIFF/WAVE reader for the STFT path: returns (sample_rate, int16 array [n_frames, channels], C-contiguous
     = interleaved, the layout sa_stft_pcm16 takes).  PCM (format tag 1, or WAVE_FORMAT_EXTENSIBLE with the PCM

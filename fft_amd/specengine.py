@@ -447,3 +447,88 @@ def analysis_panels(last_data, waveform, am_on=False, fm_on=False):
             fp["mod_index"] = "N/A"
         fp["peak_freq"] = format_freq(f[c + m.top_peak_bin]) if m.n_peaks > 0 else "---"
     return tp, fp
+
+
+# ---- the second call-site: versão15.py --------------------------------------------------------------
+def import_wav_v15(path_or_bytes):
+    """versão15.py:604-673 without the widgets: returns (last_data, entries).  last_data = {'t','y','f','Y'} with y
+    float32 (the reference's cast, :637) and Y float32 (scipy's fft of a float32 array is single precision; here the
+    transform runs in fp64 on the device and is rounded once); entries = the strings the reference writes into its
+    duration / Fc / Fs / Vpp fields (:655-664)."""
+    from . import formats
+    from .batch import fft_mag
+    fs, y = formats.read_wav_v15(path_or_bytes)
+    n = len(y)
+    vpp = np.max(y) - np.min(y)
+    duration = n / fs
+    t = np.arange(n) / fs
+    mag, _, _ = fft_mag(y.astype(np.float64), "none")
+    d = {"t": t, "y": y, "f": shifted_freq_axis(n, fs), "Y": mirror_half_to_shifted(mag, n).astype(np.float32)}
+    return d, {"duration": f"{duration:.4f}", "fc": "0", "fs": str(fs), "units_fs": "Hz", "vpp": f"{vpp:.2f}"}
+
+
+def initial_freq_view(last_data):
+    """Frequency-axis limits of versão15.py:809-819 / main.py:1313-1326: 0 .. max(5 |f[argmax Y]|, 100)."""
+    _, f0, _ = dominant_peak(last_data["f"], last_data["Y"])
+    return [0.0, max(5 * abs(f0), 100)]
+
+
+def analysis_panels_v15(last_data, waveform, am_on=False, fm_on=False):
+    """update_analysis_panels of versão15.py:1038-1180 without the widgets -> (time_panel, freq_panel) strings.
+    Differences from main.py's panel: the fundamental is np.argmax over the FULL shifted spectrum (:1101, the negative
+    twin), find_peaks(height = 5 % of max, distance = 10) runs over the full spectrum (:1108), SNR comes from the median
+    (:1126-1131), the bandwidth from `Y > A/sqrt 2` over the full array, the duty cycle from `y > max/2`.
+    Device: time statistics of y and of Y (sa_time_stats_f64), find_peaks (sa_find_peaks_f64); the few scalar read-outs
+    on top (median, first/last index above the half-power level) are taken on the host from arrays it already holds."""
+    y = np.asarray(last_data["y"])
+    t, f, Y = np.asarray(last_data["t"]), np.asarray(last_data["f"]), np.asarray(last_data["Y"])
+    tp, fp = {}, {}
+    if len(y) > 0:
+        s = time_stats(np.ascontiguousarray(y, dtype=np.float64))
+        n = len(y)
+        vpp, rms = s.max - s.min, np.sqrt(s.mean_sq)
+        crest = s.max_abs / rms if rms > 0 else 0
+        tp["vpp"], tp["rms"], tp["mean"], tp["crest_factor"] = f"{vpp:.4f} V", f"{rms:.4f} V", f"{s.mean:.4f} V", f"{crest:.4f}"
+        rate, freq = _zero_cross_freq(t, s)
+        tp["zero_crossing"] = f"{rate:.2f} Hz"
+        tp["frequency"] = f"{freq:.2f} Hz" if freq is not None else "---"
+        if waveform.startswith("Quadrada") or waveform.startswith("Pulso"):
+            tp["duty_cycle"] = f"{np.sum(y > (s.max * 0.5)) / n * 100:.1f}%"          # threshold max/2, not the mid level (:1081)
+        else:
+            tp["duty_cycle"] = "N/A"
+        tp["peak_to_rms"] = f"{crest:.4f}"
+        with np.errstate(all="ignore"):
+            tp["kurtosis"] = f"{np.float64(s.m4) / np.float64(s.m2) ** 2 - 3.0:.4f}"
+            tp["skewness"] = f"{np.float64(s.m3) / np.float64(s.m2) ** 1.5:.4f}"
+    if len(Y) > 0:
+        Y64 = np.ascontiguousarray(Y, dtype=np.float64)
+        sY = time_stats(Y64)
+        i0 = int(sY.argmax)                                                          # np.argmax(Y): first maximum (:1101)
+        f0, A = f[i0], Y[i0]
+        fp["fundamental"], fp["fund_amp"] = format_freq(f0), f"{A:.4f}"
+        peaks = find_peaks(Y64, height=sY.max * 0.05, distance=10)
+        hp = peaks[np.argsort(Y[peaks])[::-1]]
+        if len(hp) > 1:
+            hpow = np.sum(Y[hp[1:]] ** 2)
+            fp["thd"], fp["harmonics"] = f"{np.sqrt(hpow / A ** 2) * 100:.2f}%", f"{hpow / A ** 2:.4f}"
+        else:
+            fp["thd"], fp["harmonics"] = "0%", "0"
+        noise_floor = np.median(Y)
+        if noise_floor > 0:
+            fp["snr"] = f"{10 * np.log10(sY.mean_sq * len(Y) / (noise_floor ** 2 * len(Y))):.2f} dB"
+            fp["noise_floor"] = f"{noise_floor:.4f}"
+        else:
+            fp["snr"], fp["noise_floor"] = "∞ dB", "---"
+        fp["sfdr"] = f"{20 * np.log10(A / np.max(Y[hp[1:]])):.2f} dB" if len(hp) > 1 else "∞ dB"
+        bw = np.where(Y > A / np.sqrt(2))[0]
+        fp["bandwidth"] = format_freq(f[bw[-1]] - f[bw[0]]) if len(bw) > 0 else "---"
+        if am_on:
+            with np.errstate(all="ignore"):
+                fp["mod_index"] = f"{(s.max - s.min) / (s.max + s.min) * 100:.1f}%"
+        elif fm_on:
+            sb = np.where((f > f0 * 0.5) & (f < f0 * 1.5) & (f != f0))[0]
+            fp["mod_index"] = f"{np.max(Y[sb]) / A * 100:.1f}%" if len(sb) > 0 else "---"
+        else:
+            fp["mod_index"] = "N/A"
+        fp["peak_freq"] = format_freq(f[hp[1]]) if len(hp) > 1 else "---"
+    return tp, fp

@@ -591,3 +591,88 @@ def analysis_panels(last_data, waveform, am_on, fm_on):
             fp["mod_index"] = "N/A"
         fp["peak_freq"] = format_freq(hf[hp[0]]) if len(hp) > 0 else "---"
     return tp, fp
+
+
+# ---- the second call-site: versão15.py.  Pinned by tests/golden/ref_v15.* (tools/gen_golden_v15.py) ------
+def import_wav_v15(blob):
+    """versão15.py:604-673: 64-byte header, fs = uint32-LE at bytes 24..27, up to 1500 int16-LE samples,
+    y = int16.astype(float32) / 32768 (:637) -> scipy's fft then runs in single precision and 'Y' is float32."""
+    import struct
+    if len(blob) < 64:
+        raise ValueError("Arquivo muito pequeno para ser um WAV do Fnirsi 1014D")
+    fs_bytes = blob[24:28]
+    fs = struct.unpack("<I", fs_bytes)[0] if len(fs_bytes) == 4 else 1000
+    raw = blob[64:64 + 3000]
+    if len(raw) % 2 != 0:
+        raw = raw[:-1]
+    y = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    vpp = np.max(y) - np.min(y)
+    duration = len(y) / fs
+    t = np.arange(len(y)) / fs
+    Y = sfft.fftshift(sfft.fft(y))
+    f = sfft.fftshift(sfft.fftfreq(len(y), 1 / fs))
+    return ({"t": t, "y": y, "f": f, "Y": np.abs(Y)},
+            {"duration": f"{duration:.4f}", "fc": "0", "fs": str(fs), "units_fs": "Hz", "vpp": f"{vpp:.2f}"})
+
+
+def initial_freq_view(last_data):
+    """versão15.py:809-819 (main.py:1313-1326): np.argmax on the full shifted array, then |f|."""
+    f, Y = last_data["f"], last_data["Y"]
+    return [0.0, float(max(5 * abs(f[np.argmax(Y)]), 100))]
+
+
+def analysis_panels_v15(last_data, waveform, am_on, fm_on):
+    """update_analysis_panels of versão15.py:1038-1180, statement by statement."""
+    from scipy.signal import find_peaks as _fp
+    from scipy.stats import kurtosis, skew
+    y, t, f, Y = last_data["y"], last_data["t"], last_data["f"], last_data["Y"]
+    tp, fp = {}, {}
+    with np.errstate(all="ignore"):
+        if len(y) > 0:
+            vpp = np.max(y) - np.min(y)
+            rms = np.sqrt(np.mean(y ** 2))
+            tp["vpp"], tp["rms"], tp["mean"] = f"{vpp:.4f} V", f"{rms:.4f} V", f"{np.mean(y):.4f} V"
+            crest = np.max(np.abs(y)) / rms if rms > 0 else 0
+            tp["crest_factor"] = f"{crest:.4f}"
+            zc = np.where(np.diff(np.sign(y)))[0]
+            tp["zero_crossing"] = f"{len(zc) / (t[-1] - t[0]):.2f} Hz"
+            if len(zc) > 1:
+                avg_period = np.mean(np.diff(t[zc])) * 2
+                tp["frequency"] = f"{(1 / avg_period if avg_period > 0 else 0):.2f} Hz"
+            else:
+                tp["frequency"] = "---"
+            if waveform.startswith("Quadrada") or waveform.startswith("Pulso"):
+                tp["duty_cycle"] = f"{np.sum(y > (np.max(y) * 0.5)) / len(y) * 100:.1f}%"
+            else:
+                tp["duty_cycle"] = "N/A"
+            tp["peak_to_rms"] = f"{crest:.4f}"
+            tp["kurtosis"], tp["skewness"] = f"{kurtosis(y):.4f}", f"{skew(y):.4f}"
+        if len(Y) > 0:
+            i0 = np.argmax(Y)
+            f0, A = f[i0], Y[i0]
+            fp["fundamental"], fp["fund_amp"] = format_freq(f0), f"{A:.4f}"
+            peaks, _ = _fp(Y, height=np.max(Y) * 0.05, distance=10)
+            hp = peaks[np.argsort(Y[peaks])[::-1]]
+            if len(hp) > 1:
+                hpow = np.sum(Y[hp[1:]] ** 2)
+                fp["thd"], fp["harmonics"] = f"{np.sqrt(hpow / A ** 2) * 100:.2f}%", f"{hpow / A ** 2:.4f}"
+            else:
+                fp["thd"], fp["harmonics"] = "0%", "0"
+            noise_floor = np.median(Y)
+            if noise_floor > 0:
+                fp["snr"] = f"{10 * np.log10(np.sum(Y ** 2) / (noise_floor ** 2 * len(Y))):.2f} dB"
+                fp["noise_floor"] = f"{noise_floor:.4f}"
+            else:
+                fp["snr"], fp["noise_floor"] = "∞ dB", "---"
+            fp["sfdr"] = f"{20 * np.log10(A / np.max(Y[hp[1:]])):.2f} dB" if len(hp) > 1 else "∞ dB"
+            bw = np.where(Y > A / np.sqrt(2))[0]
+            fp["bandwidth"] = format_freq(f[bw[-1]] - f[bw[0]]) if len(bw) > 0 else "---"
+            if am_on:
+                fp["mod_index"] = f"{(np.max(y) - np.min(y)) / (np.max(y) + np.min(y)) * 100:.1f}%"
+            elif fm_on:
+                sb = np.where((f > f0 * 0.5) & (f < f0 * 1.5) & (f != f0))[0]
+                fp["mod_index"] = f"{np.max(Y[sb]) / A * 100:.1f}%" if len(sb) > 0 else "---"
+            else:
+                fp["mod_index"] = "N/A"
+            fp["peak_freq"] = format_freq(f[hp[1]]) if len(hp) > 1 else "---"
+    return tp, fp
