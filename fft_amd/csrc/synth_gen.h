@@ -1,6 +1,7 @@
 // synth_gen.h — device-side restatement of _generate_waveform / _apply_modulation (reference
 // main.py:536-629) shared by the fp64 GUI path (synth.hip) and the fused fp32 pipeline (synth_pipeline.hip).
 #pragma once
+#include <type_traits>
 #include <math.h>
 
 // numpy evaluates every product and sum separately; contraction into FMAs would move phases by an ulp
@@ -49,6 +50,28 @@ struct TrigF32 {
     }
     static __device__ __forceinline__ double sin(double x) { return (double)__builtin_amdgcn_sinf(turns(x)); }
     static __device__ __forceinline__ double cos(double x) { return (double)__builtin_amdgcn_cosf(turns(x)); }
+};
+
+// fp64 sine by reduction to a quarter turn and the odd Taylor polynomial to y^15 (truncation 6e-12 at pi/2): a third
+// of libm's instruction count, for the one place where the fused fp32 pipeline needs more than the hardware sine (the FM
+// prefix sum below).
+__device__ __forceinline__ double sin_poly64(double x) {
+    double t = x * 0.15915494309189535;          // turns
+    t -= rint(t);                                // [-0.5, 0.5]
+    const double at = fabs(t);
+    t = at > 0.25 ? copysign(0.5 - at, t) : t;   // sin(2 pi t) = sin(2 pi (sgn/2 - t))
+    const double y = t * 6.283185307179586, y2 = y * y;
+    double p = -7.6471637318198164759e-13;       // -1/15!
+    p = fma(p, y2, 1.6059043836821614599e-10);   //  1/13!
+    p = fma(p, y2, -2.5052108385441718775e-8);   // -1/11!
+    p = fma(p, y2, 2.7557319223985890653e-6);    //  1/9!
+    p = fma(p, y2, -1.9841269841269841270e-4);   // -1/7!
+    p = fma(p, y2, 8.3333333333333333333e-3);    //  1/5!
+    p = fma(p, y2, -1.6666666666666666667e-1);   // -1/3!
+    return fma(p * y2, y, y);
+}
+struct TrigPoly64 {
+    static __device__ __forceinline__ double sin(double x) { return sin_poly64(x); }
 };
 
 template <typename TR = TrigF64>
@@ -156,7 +179,12 @@ __device__ __forceinline__ double modulated_sample(const sa_gen_params& p, int64
     const double t = TR::time(n, p.Fs);
     const bool premod = is_premodulated(p.waveform);
     if (!premod && p.fm_on) {
-        const double acc = sin_prefix_sum<TR>(two_pi * p.Fm / p.Fs, n);
+        // The prefix sum is ALWAYS evaluated with fp64 sines: it is a product of two sines over sin(a/2) ~ 1e-3, scaled by
+        // the modulation index beta = fm_dev / Fm, so the hardware sine's ~1e-6 error would reach the phase as ~1e-6 beta
+        // rad (2e-5 at beta = 22, found by tools/soak.py); in fp64 the FM sample error no longer depends on beta.
+        // (TrigF32 -> the fp64 polynomial sine, error < 1e-11: config C4 4.05 -> 4.32 ms; libm sine: 4.61 ms.)
+        using TP = typename std::conditional<std::is_same<TR, TrigF32>::value, TrigPoly64, TrigF64>::type;
+        const double acc = sin_prefix_sum<TP>(two_pi * p.Fm / p.Fs, n);
         return TR::sin(two_pi * p.Fc * t + two_pi * p.fm_dev * acc * (1.0 / p.Fs));
     }
     double v = gen_sample<TR>(p, n, 0.5 * (double)(p.N - 1) / p.Fs);

@@ -378,7 +378,6 @@ def synth_upsample_analyze(p, vpp=None, n_base=2048, upsample=8, win="gaussian",
         y = y * (vpp / 2)
     if not q["waveform"].startswith("Onda AM") and not q["waveform"].startswith("Onda FM"):
         y = apply_modulation(q, y, t)
-    y = y.astype(np.float32).astype(np.float64)            # the device keeps base samples in fp32
     n = n_base * upsample
     if upsample > 1:
         yu = CubicSpline(t, y)(np.linspace(t[0], t[-1], n))

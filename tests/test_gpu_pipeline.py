@@ -35,6 +35,27 @@ def test_pipeline_matches_oracle(n_base, upsample):
         assert pm[i] == pytest.approx(pmref, rel=1e-3)
 
 
+def test_pipeline_fm_sample_error_independent_of_modulation_index():
+    """FM replaces y by sin(phase) with phase = 2 pi Fc t + beta-scaled prefix sum (main.py:623-627).  The oracle is fp64
+    throughout (no concession to the device's fp32 samples); the fp32 budget of a sample is: hardware sine of the final
+    phase (<= 9e-6 abs), fp32 rounding of the base samples and of the spline arithmetic (~1e-6) -> 2e-5, and it must
+    hold for every modulation index the GUI allows here, beta = fm_dev / Fm up to 50."""
+    fs, n_base = 100e3, 2048
+    params = []
+    for beta, Fm in ((0.5, 200.0), (5.0, 100.0), (22.0, 20.0), (50.0, 10.0), (50.0, 9.99), (37.3, 13.4)):
+        params.append({"duration": n_base / fs, "Fc": 3000.0 + 10 * beta, "Fs": fs, "Fm": Fm, "waveform": "Chirp Linear",
+                       "am_on": beta > 20, "am_depth": 0.7, "fm_on": True, "fm_dev": beta * Fm})
+    mag, pb, pm, y = S.synth_analyze(params, 2.0, n_base, 8, "gaussian", return_signal=True)
+    worst = []
+    for i, p in enumerate(params):
+        yu, mref, pbref, pmref = O.synth_upsample_analyze(p, 2.0, n_base, 8, "gaussian")
+        worst.append(np.abs(y[i] - yu).max())
+        assert worst[-1] < 2e-5, (i, p["fm_dev"] / p["Fm"], worst[-1])
+        assert np.linalg.norm(mag[i] - mref) / np.linalg.norm(mref) < 1e-5 * 14
+        assert pb[i] == pbref or O.top2_gap(mref[None])[0] < 1e-4
+    assert max(worst[3:]) < 2.5 * max(worst[:2]) + 2e-6          # beta = 50 is no worse than beta <= 5
+
+
 def test_pipeline_other_waveforms_and_windows():
     fs, n_base = 100e3, 2048
     base = {"duration": n_base / fs, "Fc": 2500.0, "Fs": fs, "Fm": 120.0, "am_on": False, "am_depth": 0.5, "fm_on": False, "fm_dev": 50.0}
