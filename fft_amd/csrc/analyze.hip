@@ -62,7 +62,7 @@ static int analyze_check(const T* x, int64_t batch, int32_t n, double fs) {
 template <typename T>
 static int analyze_frames_dev(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs, double side_hz,
                               T* mag_work, sa_time_stats* ts, sa_spec_metrics* sm, int32_t* peak_bin, T* peak_mag, hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     SA_TRY(analyze_check(x, batch, n, fs));
     if (batch == 0) return SA_OK;
     const int64_t nb = n / 2 + 1;
@@ -100,7 +100,7 @@ static int analyze_frames_dev(const T* x, int64_t batch, int32_t n, int32_t wind
 template <typename T>
 static int analyze_frames_host(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs, double side_hz,
                                sa_time_stats* ts, sa_spec_metrics* sm, int32_t* peak_bin, T* peak_mag) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     SA_TRY(analyze_check(x, batch, n, fs));
     if (batch == 0) return SA_OK;
     hipStream_t st = thread_stream();
@@ -201,14 +201,14 @@ int sa_analyze_frames_f64(const double* x, int64_t batch, int32_t n, int32_t win
 int sa_analyze_frames_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs,
                               double side_hz, float* mag_work, sa_time_stats* ts, sa_spec_metrics* sm,
                               int32_t* peak_bin, float* peak_mag, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     return sa::analyze_frames_dev<float>(x, batch, n, window, win_param, fs, side_hz, mag_work, ts, sm, peak_bin, peak_mag,
                                          stream ? (hipStream_t)stream : sa::thread_stream());
 }
 int sa_analyze_frames_f64_dev(const double* x, int64_t batch, int32_t n, int32_t window, double win_param, double fs,
                               double side_hz, double* mag_work, sa_time_stats* ts, sa_spec_metrics* sm,
                               int32_t* peak_bin, double* peak_mag, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     return sa::analyze_frames_dev<double>(x, batch, n, window, win_param, fs, side_hz, mag_work, ts, sm, peak_bin, peak_mag,
                                           stream ? (hipStream_t)stream : sa::thread_stream());
 }

@@ -122,6 +122,14 @@ static void fill_filter(void* host, void* ctx) {     // b[k] = conj(c[|k|]) wrap
 
 struct BluPlan { const Cd* chirp; const Cd* fb; int64_t M; };
 
+static std::mutex g_blu_mu;
+static std::map<std::pair<int, int64_t>, Cd*> g_blu_cache;
+void free_bluestein_cache() {               // sa_shutdown (no call is in flight: runtime.hip closes the gate first)
+    std::lock_guard<std::mutex> lk(g_blu_mu);
+    for (auto& kv : g_blu_cache) (void)hipFree(kv.second);
+    g_blu_cache.clear();
+}
+
 static int get_blu_plan(int64_t n, hipStream_t st, BluPlan* p) {
     int64_t M = 1;
     while (M < 2 * n - 1) M <<= 1;
@@ -130,9 +138,9 @@ static int get_blu_plan(int64_t n, hipStream_t st, BluPlan* p) {
     ChirpCtx c{n, M};
     p->chirp = static_cast<const Cd*>(get_cached_table("blu_chirp:" + std::to_string(n), (size_t)n * 16, fill_chirp, &c));
     if (!p->chirp) return SA_EHIP;
-    // FFT of the filter: computed once per n on the device, cached as a table keyed by n
-    static std::mutex mu;
-    static std::map<std::pair<int, int64_t>, Cd*> cache;
+    // FFT of the filter: computed once per n on the device, cached as a table keyed by (device, n)
+    std::mutex& mu = g_blu_mu;
+    std::map<std::pair<int, int64_t>, Cd*>& cache = g_blu_cache;
     int dev = 0;
     hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
@@ -141,7 +149,7 @@ static int get_blu_plan(int64_t n, hipStream_t st, BluPlan* p) {
     std::vector<double> hb((size_t)M * 2);
     fill_filter(hb.data(), &c);
     Cd* dfb = nullptr;
-    SA_HIP(hipMalloc(&dfb, (size_t)M * 16));        // the cached table itself: lives until process exit
+    SA_HIP(hipMalloc(&dfb, (size_t)M * 16));        // the cached table itself: lives until sa_shutdown
     int rc = SA_OK;
     {
         Temp tmp;
@@ -154,7 +162,7 @@ static int get_blu_plan(int64_t n, hipStream_t st, BluPlan* p) {
         if (rc != SA_OK) (void)hipStreamSynchronize(st);   // hb / the arena must not be released under a copy in flight
     }
     if (rc != SA_OK) { hipFree(dfb); return rc; }
-    cache[{dev, n}] = dfb;       // lives until process exit
+    cache[{dev, n}] = dfb;       // freed by free_bluestein_cache (sa_shutdown)
     p->fb = dfb;
     return SA_OK;
 }
@@ -227,7 +235,7 @@ int fft_mag_any_dev(const double* dx, int64_t cnt, int64_t n, int window, double
 extern "C" int sa_fft_mag_f64(const double* x, int64_t batch, int64_t n, int32_t window, double win_param, int32_t flags,
                               double* mag, int32_t* peak_bin, double* peak_mag) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (n < 1 || n > (1LL << 26)) { set_error("sa_fft_mag_f64: n=%lld out of range [1, 2^26]", (long long)n); return SA_EINVAL; }
     if (batch < 0) { set_error("sa_fft_mag_f64: batch < 0"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;

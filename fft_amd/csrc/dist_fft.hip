@@ -211,7 +211,7 @@ extern "C" {
 
 int sa_dist_plan_create(sa_dist_plan** plan_out, int64_t n, int32_t n_ranks, const int32_t* devices, int32_t flags) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (!plan_out) { set_error("sa_dist_plan_create: plan is NULL"); return SA_EINVAL; }
     *plan_out = nullptr;
     int L = 0;
@@ -531,7 +531,7 @@ done:
 
 int sa_fft_c2c_f64_dist(const double* in_ri, double* out_ri, int64_t n, int32_t n_ranks, int32_t flags, sa_dist_stats* stats) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (!in_ri || !out_ri) { set_error("sa_fft_c2c_f64_dist: NULL buffer"); return SA_EINVAL; }
     if (n_ranks == 0) {                                      // 0 = one rank per visible device (rounded down to a power of two)
         int nd = 0;

@@ -373,7 +373,7 @@ static int set_pass_twiddles(C2cArgs& a, int64_t mp) {
 }
 
 int c2c_f64_dev(const double* in, double* out, double* work, int64_t n, int64_t batch, int32_t flags, hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     int L = 0;
     while ((1LL << L) < n) ++L;
     if (n < 2 || (1LL << L) != n || L > 30) { set_error("c2c f64: n=%lld must be a power of two in [2, 2^30]", (long long)n); return SA_EUNSUP; }
@@ -511,7 +511,7 @@ extern "C" {
 
 int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_t n, int64_t batch, int32_t flags,
                        void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     if (!in_ri || !out_ri) { sa::set_error("sa_fft_c2c_f64_dev: NULL buffer"); return SA_EINVAL; }
     if (flags & ~3) { sa::set_error("sa_fft_c2c_f64_dev: unknown flag bits"); return SA_EINVAL; }
     hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
@@ -519,7 +519,7 @@ int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_
 }
 
 int sa_fft_c2c_f64(const double* in_ri, double* out_ri, int64_t n, int64_t batch, int32_t flags) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     if (!in_ri || !out_ri) { sa::set_error("sa_fft_c2c_f64: NULL buffer"); return SA_EINVAL; }
     if (flags & ~3) { sa::set_error("sa_fft_c2c_f64: unknown flag bits"); return SA_EINVAL; }
     if (batch <= 0 || n <= 0) { if (batch == 0) return SA_OK; sa::set_error("sa_fft_c2c_f64: bad n/batch"); return SA_EINVAL; }

@@ -530,7 +530,7 @@ static bool launch_regs_kernel(const float* y, int64_t batch, int64_t n, int64_t
 
 template <typename T>
 static int time_stats_dev(const T* y, int64_t batch, int64_t n, int64_t stride, sa_time_stats* out, hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch < 0 || n < 1) { set_error("time_stats: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;
     if (!y || !out) { set_error("time_stats: NULL buffer"); return SA_EINVAL; }
@@ -546,7 +546,7 @@ static int time_stats_dev(const T* y, int64_t batch, int64_t n, int64_t stride, 
 template <typename T>
 static int spectral_metrics_dev(const T* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
                                 sa_spec_metrics* out, hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch < 0 || n < 1) { set_error("spectral_metrics: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;
     if (!mag || !out) { set_error("spectral_metrics: NULL buffer"); return SA_EINVAL; }
@@ -563,7 +563,7 @@ static int spectral_metrics_dev(const T* mag, int64_t batch, int64_t n, double f
 
 static int find_peaks_dev(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel, int32_t distance,
                           int32_t max_peaks, int32_t* idx, int32_t* count, uint8_t* state, hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch < 0 || n < 1 || max_peaks < 1 || distance < 1) {
         set_error("find_peaks: need batch >= 0, n >= 1, max_peaks >= 1, distance >= 1");
         return SA_EINVAL;
@@ -626,16 +626,16 @@ int sa_find_peaks_f64_noalloc_dev(const double* x, int64_t batch, int64_t n, dou
 }
 
 int sa_time_stats_f32_dev(const float* y, int64_t batch, int64_t n, int64_t frame_stride, sa_time_stats* out, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     return sa::time_stats_dev<float>(y, batch, n, frame_stride, out, stream ? (hipStream_t)stream : sa::thread_stream());
 }
 int sa_time_stats_f64_dev(const double* y, int64_t batch, int64_t n, int64_t frame_stride, sa_time_stats* out, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     return sa::time_stats_dev<double>(y, batch, n, frame_stride, out, stream ? (hipStream_t)stream : sa::thread_stream());
 }
 int sa_time_stats_f64(const double* y, int64_t batch, int64_t n, sa_time_stats* out) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch < 0 || n < 1) { set_error("time_stats: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;
     if (!y || !out) { set_error("time_stats: NULL buffer"); return SA_EINVAL; }
@@ -656,14 +656,14 @@ int sa_time_stats_f64(const double* y, int64_t batch, int64_t n, sa_time_stats* 
 
 int sa_find_peaks_f64_dev(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel, int32_t distance,
                           int32_t max_peaks, int32_t* idx, int32_t* count, uint8_t* work, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     return sa::find_peaks_dev(x, batch, n, height_abs, height_rel, distance, max_peaks, idx, count, work,
                               stream ? (hipStream_t)stream : sa::thread_stream());
 }
 int sa_find_peaks_f64(const double* x, int64_t batch, int64_t n, double height_abs, double height_rel, int32_t distance,
                       int32_t max_peaks, int32_t* idx, int32_t* count) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch < 0 || n < 1 || max_peaks < 1 || distance < 1) {
         set_error("find_peaks: need batch >= 0, n >= 1, max_peaks >= 1, distance >= 1");
         return SA_EINVAL;
@@ -695,17 +695,17 @@ int sa_find_peaks_f64(const double* x, int64_t batch, int64_t n, double height_a
 
 int sa_spectral_metrics_f32_dev(const float* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
                                 sa_spec_metrics* out, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     return sa::spectral_metrics_dev<float>(mag, batch, n, freq_step, side_hz, out, stream ? (hipStream_t)stream : sa::thread_stream());
 }
 int sa_spectral_metrics_f64_dev(const double* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
                                 sa_spec_metrics* out, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     return sa::spectral_metrics_dev<double>(mag, batch, n, freq_step, side_hz, out, stream ? (hipStream_t)stream : sa::thread_stream());
 }
 int sa_spectral_metrics_f64(const double* mag, int64_t batch, int64_t n, double freq_step, double side_hz, sa_spec_metrics* out) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch < 0 || n < 1) { set_error("spectral_metrics: batch must be >= 0 and n >= 1"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;
     if (!mag || !out) { set_error("spectral_metrics: NULL buffer"); return SA_EINVAL; }

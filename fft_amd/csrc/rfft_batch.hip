@@ -191,7 +191,7 @@ static int check_args(const T* x, int64_t batch, int32_t n, int32_t window, int3
 template <typename T>
 int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32_t n, int32_t window, double win_param,
                           int32_t flags, T* mag, int32_t* peak_bin, T* peak_mag, hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     int log2n = 0;
     SA_TRY(check_args(x, batch, n, window, flags, mag, peak_bin, peak_mag, &log2n));
     if (batch == 0) return SA_OK;
@@ -227,7 +227,7 @@ template int rfft_peak_dev<float>(const float*, int64_t, int32_t, int32_t, doubl
 int rfft4096_metrics_dev(const float* x, int64_t batch, int32_t window, double win_param, int32_t flags, float* mag,
                          int32_t* peak_bin, float* peak_mag, sa_time_stats* ts, sa_spec_metrics* sm, double freq_step,
                          double side_hz, hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     int log2n = 0;
     SA_TRY(check_args(x, batch, 4096, window, flags, mag, peak_bin, peak_mag, &log2n));
     if (flags & SA_F_DB) { set_error("fused metrics need the linear spectrum (SA_F_DB not allowed)"); return SA_EINVAL; }
@@ -286,7 +286,7 @@ int rfft4096_metrics_dev(const float* x, int64_t batch, int32_t window, double w
 template <typename T>
 int rfft_peak_host(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
                    T* mag, int32_t* peak_bin, T* peak_mag) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     int log2n = 0;
     SA_TRY(check_args(x, batch, n, window, flags, mag, peak_bin, peak_mag, &log2n));
     if (batch == 0) return SA_OK;
@@ -471,13 +471,13 @@ extern "C" {
 
 int sa_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
                          float* mag, int32_t* peak_bin, float* peak_mag, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
     return sa::rfft_peak_dev<float>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
 }
 int sa_rfft_peak_f64_dev(const double* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags,
                          double* mag, int32_t* peak_bin, double* peak_mag, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
     return sa::rfft_peak_dev<double>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
 }
@@ -493,7 +493,7 @@ int sa_rfft_peak_f64(const double* x, int64_t batch, int32_t n, int32_t window, 
 int sa_time_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t window, double win_param,
                               int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, int32_t iters,
                               float* ms_avg) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     if (iters <= 0 || !ms_avg) { sa::set_error("iters must be > 0 and ms_avg non-NULL"); return SA_EINVAL; }
     hipStream_t st = sa::thread_stream();
     hipEvent_t e0, e1;
@@ -517,7 +517,7 @@ int sa_time_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t 
 }
 
 int sa_fill_tone_noise_f32_dev(float* x, int64_t batch, int32_t n, double fs, uint64_t seed, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     if (!x || batch < 0 || n < 4 || (n & 3)) { sa::set_error("sa_fill_tone_noise_f32_dev: bad arguments"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;
     hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();

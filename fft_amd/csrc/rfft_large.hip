@@ -122,7 +122,7 @@ constexpr int RL_MAX_LOG2N = 29;
 template <typename T>
 int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags, T* mag,
                    int32_t* peak_bin, T* peak_mag, hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     int L = 0;
     while ((1LL << L) < n) ++L;
     if (n < 8192 || (1LL << L) != n || L > RL_MAX_LOG2N) {

@@ -34,6 +34,27 @@ int allow_dynamic_lds(const void* kernel, int bytes, uint64_t* devs);
         }                                                                                    \
     } while (0)
 
+// Every entry point (and the internal functions that may be reached first) opens with SA_ENTER(): lazy init plus a
+// guard that marks this thread as inside the library until the function returns.  sa_shutdown waits for all guards
+// to go before it frees plans, tables and arenas, and holds new calls at the door meanwhile, so a thread can never be
+// left with a freed RfftPlan* / table pointer.  Guards nest per thread; shard workers run their task inside
+// their caller's guard (NestedCall).
+struct ActiveCall {
+    ActiveCall();
+    ~ActiveCall();
+    ActiveCall(const ActiveCall&) = delete;
+    ActiveCall& operator=(const ActiveCall&) = delete;
+};
+struct NestedCall {            // a helper thread working on behalf of a caller that already holds a guard
+    NestedCall();
+    ~NestedCall();
+};
+void close_gate_and_drain();   // sa_shutdown: no new outermost calls; returns when none is in flight
+void open_gate();
+#define SA_ENTER()                       \
+    ::sa::ActiveCall sa_active_call_;    \
+    SA_TRY(::sa::ensure_init())
+
 #define SA_TRY(expr)                 \
     do {                             \
         int rc_ = (expr);            \
@@ -63,6 +84,7 @@ const RfftPlan* get_rfft_plan(bool f64, int n, int window, double win_param);
 const void* get_cached_table(const std::string& key, size_t bytes, void (*fill)(void* host, void* ctx), void* ctx);
 
 void free_all_plans();
+void free_bluestein_cache();        // bluestein.hip: filter spectra cached per (device, n)
 
 // Per-call temporary device / pinned-host memory for the host-pointer entry points.  Requests are served by
 // bump allocation from a block cached per host thread (so the GUI's frame-at-a-time calls pay no hipMalloc /

@@ -10,6 +10,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <tuple>
 
 namespace sa {
@@ -25,6 +26,30 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- calls in flight vs sa_shutdown (see runtime.h: SA_ENTER) ------------------------------------------------------------
+static std::atomic<int> g_active{0};
+static std::atomic<bool> g_closing{false};
+static thread_local int t_call_depth = 0;
+ActiveCall::ActiveCall() {
+    if (t_call_depth++ > 0) return;
+    for (;;) {
+        g_active.fetch_add(1, std::memory_order_acq_rel);
+        if (!g_closing.load(std::memory_order_acquire)) return;
+        g_active.fetch_sub(1, std::memory_order_acq_rel);          // a shutdown is draining: wait outside
+        while (g_closing.load(std::memory_order_acquire)) std::this_thread::yield();
+    }
+}
+ActiveCall::~ActiveCall() {
+    if (--t_call_depth == 0) g_active.fetch_sub(1, std::memory_order_acq_rel);
+}
+NestedCall::NestedCall() { ++t_call_depth; }
+NestedCall::~NestedCall() { --t_call_depth; }
+void close_gate_and_drain() {
+    g_closing.store(true, std::memory_order_release);
+    while (g_active.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+}
+void open_gate() { g_closing.store(false, std::memory_order_release); }
 
 int num_cus() { return g_ncus; }
 bool initialised() { return g_inited.load(std::memory_order_acquire); }
@@ -395,14 +420,24 @@ int sa_init(int device) {
 }
 
 void sa_shutdown(void) {
-    sa::shard_shutdown();
-    hipDeviceSynchronize();
+    static std::mutex one_at_a_time;
+    std::lock_guard<std::mutex> l(one_at_a_time);
+    sa::shard_shutdown();                    // lets a sharded call in flight finish, then stops the workers
+    sa::close_gate_and_drain();              // no thread is inside the library past this point, none can enter
+    int ndev = 0, cur = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && hipGetDevice(&cur) == hipSuccess) {
+        for (int d = 0; d < ndev; ++d)       // work queued by *_dev calls may still be running on any device
+            if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+        (void)hipSetDevice(cur);
+    }
     sa::free_thread_caches();
     sa::free_all_plans();
+    sa::free_bluestein_cache();
+    sa::open_gate();
 }
 
 int sa_dev_alloc(void** dptr, uint64_t bytes) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     if (!dptr) { sa::set_error("sa_dev_alloc: dptr is NULL"); return SA_EINVAL; }
     SA_HIP(hipMalloc(dptr, bytes ? bytes : 1));
     return SA_OK;
@@ -422,7 +457,7 @@ int sa_memcpy_d2h(void* dst, const void* src, uint64_t bytes) {
 int sa_thread_state_count(void) { return sa::thread_state_count(); }
 
 int sa_sync(void) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     SA_HIP(hipStreamSynchronize(sa::thread_stream()));
     return SA_OK;
 }

@@ -58,6 +58,7 @@ void worker_main(Worker* w) {
             rc = SA_EHIP;
             msg = "shard worker could not bind device " + std::to_string(w->dev);
         } else {
+            NestedCall inside_callers_guard;                    // the dispatching thread holds the guard for all shards
             rc = lo < hi ? (*fn)(lo, hi) : SA_OK;
             if (rc != SA_OK) msg = sa_last_error();               // this thread's message travels with the result
         }
@@ -100,7 +101,7 @@ int shard_configure(const int32_t* devices, int32_t count) {
     if (count < 0 || count > 64) { set_error("sa_shard_devices: count %d out of range [0, 64]", count); return SA_EINVAL; }
     int ndev = 0;
     if (count > 0) {
-        SA_TRY(ensure_init());
+        SA_ENTER();
         SA_HIP(hipGetDeviceCount(&ndev));
         for (int i = 0; i < count; ++i) {
             const int d = devices ? devices[i] : i % ndev;
@@ -135,6 +136,7 @@ static void shard_block(int64_t total, int s, int g, int64_t* lo, int64_t* hi) {
 }
 
 int run_sharded(int64_t total, const std::function<int(int64_t, int64_t)>& fn) {
+    ActiveCall guard;                                      // held by the dispatching thread on behalf of every shard
     Pool& p = pool();
     std::lock_guard<std::mutex> d(p.dispatch);
     std::vector<Worker*> ws;

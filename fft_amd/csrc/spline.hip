@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(64) cubic_upsample_kernel(const double* __rest
 
 int cubic_upsample_dev(const double* t, const double* y, int64_t batch, int32_t m, int32_t n_out, double* t_out, double* y_out,
                        hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch < 0 || m < 2 || n_out < 1) { set_error("cubic_upsample: need batch >= 0, m >= 2 knots, n_out >= 1"); return SA_EINVAL; }
     if (m > SPLINE_MAX_KNOTS) { set_error("cubic_upsample: m=%d knots exceed the supported %d", m, SPLINE_MAX_KNOTS); return SA_EUNSUP; }
     if (batch == 0) return SA_OK;
@@ -121,13 +121,13 @@ extern "C" {
 
 int sa_cubic_upsample_f64_dev(const double* t, const double* y, int64_t batch, int32_t m, int32_t n_out, double* t_out,
                               double* y_out, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     return sa::cubic_upsample_dev(t, y, batch, m, n_out, t_out, y_out, stream ? (hipStream_t)stream : sa::thread_stream());
 }
 
 int sa_cubic_upsample_f64(const double* t, const double* y, int64_t batch, int32_t m, int32_t n_out, double* t_out, double* y_out) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch < 0 || m < 2 || n_out < 1) { set_error("cubic_upsample: need batch >= 0, m >= 2 knots, n_out >= 1"); return SA_EINVAL; }
     if (m > SPLINE_MAX_KNOTS) { set_error("cubic_upsample: m=%d knots exceed the supported %d", m, SPLINE_MAX_KNOTS); return SA_EUNSUP; }
     if (batch == 0) return SA_OK;

@@ -266,7 +266,7 @@ static int launch_stereo(const StftArgs& a, hipStream_t st) {
 int stft_pcm16_dev(const int16_t* pcm, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop, int32_t window,
                    double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, float* scratch,
                    hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     int lr = 0;
     while ((1 << lr) < nfft) ++lr;
     if (nfft < 16 || (1 << lr) != nfft || nfft > 16384) { set_error("stft: nfft=%d must be a power of two in [16, 16384]", nfft); return SA_EUNSUP; }
@@ -329,7 +329,7 @@ int64_t sa_stft_num_frames(int64_t n_samples, int32_t nfft, int32_t hop) {
 int sa_stft_pcm16_dev(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop,
                       int32_t window, double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag,
                       float* scratch, void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
     return sa::stft_pcm16_dev(interleaved, n_samples, channels, nfft, hop, window, win_param, flags, mag, peak_bin, peak_mag,
                               scratch, st);
@@ -383,7 +383,7 @@ static int stft_host_range(const int16_t* interleaved, int32_t channels, int32_t
 extern "C" int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop, int32_t window,
                              double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (channels < 1 || nfft < 1 || hop < 1) { set_error("stft: bad channels/nfft/hop"); return SA_EINVAL; }
     const int64_t nframes = sa_stft_num_frames(n_samples, nfft, hop);
     if (nframes == 0) return SA_OK;

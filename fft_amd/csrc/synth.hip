@@ -84,7 +84,7 @@ extern "C" {
 
 int sa_synth_f64(const sa_gen_params* p, double* t_out, double* y_out) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     SA_TRY(check_params(p));
     if (!y_out) { set_error("sa_synth_f64: y_out is NULL"); return SA_EINVAL; }
     hipStream_t st = thread_stream();
@@ -105,7 +105,7 @@ int sa_synth_f64(const sa_gen_params* p, double* t_out, double* y_out) {
 int sa_compute_f64(const sa_gen_params* p, int32_t window, double win_param, int32_t flags, double* t_out, double* y_out,
                    double* mag, int32_t* peak_bin, double* peak_mag) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     SA_TRY(check_params(p));
     if (!y_out || !mag || !peak_bin || !peak_mag) { set_error("sa_compute_f64: NULL output buffer"); return SA_EINVAL; }
     if (window < SA_WIN_NONE || window > SA_WIN_LAST) { set_error("unknown window id %d", window); return SA_EINVAL; }

@@ -283,7 +283,7 @@ static int launch_pipe(const PipeArgs& a, hipStream_t st) {
 int synth_analyze_dev(const sa_gen_params* dparams, int64_t batch, int32_t n_base, int32_t upsample, int32_t window,
                       double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, float* y_out,
                       hipStream_t st) {
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch <= 0) return batch == 0 ? SA_OK : (set_error("batch < 0"), SA_EINVAL);
     if (upsample != 1 && upsample != 8) { set_error("synth_analyze: upsample must be 1 or 8"); return SA_EUNSUP; }
     const int64_t n = (int64_t)n_base * upsample;
@@ -336,7 +336,7 @@ extern "C" {
 int sa_synth_analyze_dev(const sa_gen_params* params_dev, int64_t batch, int32_t n_base, int32_t upsample, int32_t window,
                          double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, float* y_out,
                          void* stream) {
-    SA_TRY(sa::ensure_init());
+    SA_ENTER();
     hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
     return sa::synth_analyze_dev(params_dev, batch, n_base, upsample, window, win_param, flags, mag, peak_bin, peak_mag, y_out, st);
 }
@@ -359,7 +359,7 @@ int sa_synth_analyze(const sa_gen_params* params, int64_t batch, int32_t n_base,
 static int synth_analyze_host(const sa_gen_params* params, int64_t batch, int32_t n_base, int32_t upsample, int32_t window,
                               double win_param, int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag, float* y_out) {
     using namespace sa;
-    SA_TRY(ensure_init());
+    SA_ENTER();
     if (batch < 0) { set_error("batch < 0"); return SA_EINVAL; }
     if (batch == 0) return SA_OK;
     if (!params) { set_error("synth_analyze: params is NULL"); return SA_EINVAL; }
