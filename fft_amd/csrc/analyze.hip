@@ -74,24 +74,30 @@ static int analyze_frames_dev(const T* x, int64_t batch, int32_t n, int32_t wind
         if (!pb) { pb = static_cast<int32_t*>(tmp.dev((size_t)batch * sizeof(int32_t))); if (!pb) return SA_ENOMEM; borrowed = true; }
         if (!pm) { pm = static_cast<T*>(tmp.dev((size_t)batch * sizeof(T))); if (!pm) return SA_ENOMEM; borrowed = true; }
     }
+    // One exit: whenever scratch came from the arena — or anything failed after work was queued — the stream is
+    // synchronised before `tmp` hands the blocks back (the next call on this thread bump-allocates the same bytes).
+    int rc = SA_OK;
     if (fused_4096<T>(n) && (ts || sm) && pb && (reinterpret_cast<uintptr_t>(x) % 16) == 0) {   // 16-byte loads per lane
         // 4096-point fp32 frames whose transform is wanted anyway: statistics and metrics are computed inside the
         // transform kernel, from the load registers and from the spectrum row in LDS — one read of the frames, no
         // spectrum traffic at all
-        SA_TRY(run_fused(x, batch, window, win_param, pb, pm, ts, sm, fs / n, side_hz, st));
+        rc = run_fused(x, batch, window, win_param, pb, pm, ts, sm, fs / n, side_hz, st);
     } else {
         if (sm && !mag_work) {
             mag_work = static_cast<T*>(tmp.dev((size_t)batch * nb * sizeof(T)));
-            if (!mag_work) return SA_ENOMEM;
+            if (!mag_work) rc = SA_ENOMEM;
             borrowed = true;
         }
-        if (sm || peak_bin || peak_mag)
-            SA_TRY(Entry<T>::rfft(x, batch, n, window, win_param, sm ? SA_F_WRITE_MAG : 0, sm ? mag_work : nullptr, pb, pm, st));
-        if (ts) SA_TRY(Entry<T>::tstats(x, batch, n, ts, st));
-        if (sm) SA_TRY(Entry<T>::smet(mag_work, batch, n, fs / n, side_hz, sm, st));
+        if (rc == SA_OK && (sm || peak_bin || peak_mag))
+            rc = Entry<T>::rfft(x, batch, n, window, win_param, sm ? SA_F_WRITE_MAG : 0, sm ? mag_work : nullptr, pb, pm, st);
+        if (rc == SA_OK && ts) rc = Entry<T>::tstats(x, batch, n, ts, st);
+        if (rc == SA_OK && sm) rc = Entry<T>::smet(mag_work, batch, n, fs / n, side_hz, sm, st);
     }
-    if (borrowed) SA_HIP(hipStreamSynchronize(st));     // fully asynchronous only when the caller brings every buffer
-    return SA_OK;
+    if (borrowed || rc != SA_OK) {                      // fully asynchronous only when the caller brings every buffer
+        const hipError_t e = hipStreamSynchronize(st);
+        if (rc == SA_OK && e != hipSuccess) { set_error("analyze_frames: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+    }
+    return rc;
 }
 
 // Host-pointer form: 64 MiB input chunks, two buffer sets.  The upload dominates (16 KiB per frame up, ~220 bytes
@@ -138,9 +144,14 @@ static int analyze_frames_host(const T* x, int64_t batch, int32_t n, int32_t win
         return SA_OK;
     };
     if (NSET == 1) {
-        SA_HIP(hipMemcpyAsync(sets[0].x, x, (size_t)batch * n * sizeof(T), hipMemcpyHostToDevice, st));
-        SA_TRY(run_chunk(sets[0], batch));
-        return download(sets[0], 0, batch);
+        auto one = [&]() -> int {
+            SA_HIP(hipMemcpyAsync(sets[0].x, x, (size_t)batch * n * sizeof(T), hipMemcpyHostToDevice, st));
+            SA_TRY(run_chunk(sets[0], batch));
+            return download(sets[0], 0, batch);
+        };
+        const int rc1 = one();
+        if (rc1 != SA_OK) (void)hipStreamSynchronize(st);       // nothing queued may outlive the arena blocks
+        return rc1;
     }
     hipStream_t up = nullptr;
     SA_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));

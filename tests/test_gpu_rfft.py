@@ -139,6 +139,33 @@ def test_flags_db_exclude_and_peak_only():
     assert none_mag is None and (pb3 == 100).all()
 
 
+@pytest.mark.parametrize("n", [2048, 4096, 8192])
+def test_db_mode_matches_oracle_every_kernel_family(n):
+    """20 log10(max(|Y|, floor)) through the tuned 4096-point kernel (its dB epilogue uses the hardware log2 path), the
+    generic kernels either side of it, and the library-libm path: all against the oracle's numpy expression over 12
+    decades of level, to 2e-4 dB (fp32 magnitudes: 1e-6 relative = 9e-6 dB; the fast logarithm adds < 1e-4 dB)."""
+    import fft_amd
+    rng = np.random.default_rng(n)
+    t = np.arange(n)
+    amp = 10.0 ** rng.uniform(-6, 6, size=(23, 1))
+    x = (amp * (np.sin(2 * np.pi * rng.uniform(3, n / 2 - 3, (23, 1)) * t / n) + 1e-3 * rng.standard_normal((23, n)))).astype(np.float32)
+    x[5] = 0.0                                                    # all-zero frame: every bin at the floor, -600 dB
+    magdb, pb, pm = fft_amd.rfft_peak(x, "hann", db=True)
+    ref, pbref, _ = O.rfft_mag_peak(x, "hann", db=True)
+    lin, _, _ = O.rfft_mag_peak(x, "hann")
+    # vs the oracle on the bins that stand clear of the frame's fp32 rounding residue (1e-6 of the largest bin is
+    # 1e-6 / 0.05 relative there = 2e-4 dB) ...
+    sel = lin > 0.05 * lin.max(axis=1, keepdims=True)
+    assert sel.sum() > 23 and np.abs(magdb - ref)[sel].max() < 1e-3
+    assert np.all(magdb[5] == pytest.approx(-600.0, abs=1e-3))
+    np.testing.assert_array_equal(np.delete(pb, 5), np.delete(pbref, 5))
+    # ... and, on EVERY bin, against the logarithm of the linear spectrum the same kernel family writes: this isolates
+    # the dB conversion itself (hardware log2 path vs libm) from the transform's rounding
+    mag, _, _ = fft_amd.rfft_peak(x, "hann")
+    live = mag > 0
+    assert np.abs(magdb[live] - 20 * np.log10(np.maximum(mag[live].astype(np.float64), 1e-30))).max() < 2e-4
+
+
 def test_kats_impulse_dc_nyquist_ties():
     import fft_amd
     n = 4096
