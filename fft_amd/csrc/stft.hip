@@ -109,10 +109,18 @@ stft_stereo_kernel(StftArgs a) {
                 for (int n1 = 0; n1 < R0; ++n1) raw[u * R0 + n1] = src[n1 * (N / R0) + TPF * u];
         }
     };
-    // frames past the end repeat the last frame (every thread reaches the barriers); their stores are dropped
-    const int64_t first = (int64_t)blockIdx.x * FPW;
-    if (first < a.nframes) load_frame(first + g <= last ? first + g : last, tl);
-    for (int64_t base = first; base < a.nframes; base += (int64_t)gridDim.x * FPW) {
+    // frames past the end repeat the last frame (every thread reaches the barriers); their stores are dropped.
+    // Frame -> workgroup map: blocks b and b + 8 share an XCD (and its L2; observed placement, used for speed only), so
+    // each residue class b % 8 walks its own CONTIGUOUS eighth of the frames: the workgroups running on an XCD at any
+    // time then work on neighbouring frames, whose (nfft - hop) / nfft overlap is fetched into that L2 once instead
+    // of once per XCD (hop = nfft / 4: the same samples used to be fetched by four different L2s).
+    const int64_t units = (a.nframes + FPW - 1) / FPW, per_xcd = (units + 7) / 8;
+    const int64_t xcd_first = (int64_t)(blockIdx.x & 7) * per_xcd, slot_step = gridDim.x >> 3;   // gridDim.x % 8 == 0 (host)
+    const int64_t slot0 = blockIdx.x >> 3;
+    const int64_t first = (xcd_first + slot0) * FPW;
+    if (slot0 < per_xcd) load_frame(first + g <= last ? first + g : last, tl);
+    for (int64_t slot = slot0; slot < per_xcd; slot += slot_step) {
+        const int64_t base = (xcd_first + slot) * FPW;
         const bool valid = base + g <= last;
         const int64_t f = valid ? base + g : last;
         int tq = tl;                             // opaque per frame: nothing below is hoisted out of the loop
@@ -123,7 +131,7 @@ stft_stereo_kernel(StftArgs a) {
         for (int i = 0; i < P; ++i)
             v[i] = mk<float>((float)(int16_t)(raw[i] & 0xFFFF) * w[i], (float)(int16_t)(raw[i] >> 16) * w[i]);
         {
-            const int64_t nb_ = base + (int64_t)gridDim.x * FPW + g;            // next round's frame (clamped, L2-hot, unused at the end)
+            const int64_t nb_ = base + slot_step * FPW + g;                     // next round's frame (clamped, L2-hot, unused at the end)
             load_frame(nb_ <= last ? nb_ : last, tq);
         }
         lds_fft_tw<float, LR, PP>(v, buf, tl, tw);
@@ -242,7 +250,8 @@ static int launch_stereo_pp(const StftArgs& a, hipStream_t st) {
     auto kern = stft_stereo_kernel<LR, PP>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
-    const int64_t cap = grid_cap(64, "STFT"), need = (a.nframes + FPW - 1) / FPW;
+    // a multiple of 8 workgroups (the kernel deals each residue class mod 8 its own contiguous range of frames)
+    const int64_t cap = (grid_cap(64, "STFT") + 7) / 8 * 8, need = ((a.nframes + FPW - 1) / FPW + 7) / 8 * 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)(need < cap ? need : cap)), dim3(FftPlan<LR, PP>::TPF * FPW), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o t --output-format csv -- python3 $ROOT/tools/bench_configs.py $CFG > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_trace.err
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_WAIT_ANY" "GRBM_GUI_ACTIVE"; do
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_WAIT_ANY" "GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)
   timeout -s KILL 120 rocprofv3 --pmc $pass -d $OUT/${TAG}_pmc_$name -o p --output-format csv -- python3 $ROOT/tools/bench_configs.py $CFG > /dev/null 2> $OUT/${TAG}_pmc_$name.err
 done
