@@ -33,7 +33,13 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int R4K_SLAB_BYTES = 8 * 136 * 8;         // 8704 B private exchange slab per wave
 constexpr int r4k_wtab_bytes(bool half) { return half ? 2048 * 4 : 4096 * 4; }
-constexpr int r4k_lds_bytes(int waves, bool half = false) { return r4k_wtab_bytes(half) + waves * R4K_SLAB_BYTES + 6 * 64 * 8; }
+// pass-2 twiddle powers w_128^{g k}, g = lane & 7, k = 0..15: rows of 17 float2 (the odd stride keeps the 8 rows a
+// wave reads at once on distinct banks).  R4K_TW2_TABLE=0 (build-time A/B aid) derives them with the product tree.
+#ifndef R4K_TW2_TABLE
+#define R4K_TW2_TABLE 1
+#endif
+constexpr int R4K_TW2_BYTES = R4K_TW2_TABLE ? 8 * 17 * 8 : 0;
+constexpr int r4k_lds_bytes(int waves, bool half = false) { return r4k_wtab_bytes(half) + waves * R4K_SLAB_BYTES + 6 * 64 * 8 + R4K_TW2_BYTES; }
 
 __device__ __forceinline__ void wave_lds_fence() {
     // Orders this wave's LDS accesses for the compiler; the hardware executes one wave's DS
@@ -61,6 +67,13 @@ __device__ __forceinline__ void apply_twiddles16(float2* v, float2 w) {
     v[13] = cmul(v[13], cmul(p8, p5));
     v[14] = cmul(v[14], cmul(p8, p6));
     v[15] = cmul(v[15], cmul(p8, p7));
+}
+
+// v[k] *= row[k], k = 1..15: the powers come from an LDS table (15 ds_read_b64, conflict free) instead of 14 complex
+// multiplies of the product tree — the LDS pipe has the room (~770 of ~2000 cycles per frame), the VALU does not.
+__device__ __forceinline__ void apply_twiddles16_tab(float2* v, const float2* row) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], row[k]);
 }
 
 // Wave-wide reductions on the VALU cross-lane path (DPP), result in every lane: 6 dependent VALU ops
@@ -120,14 +133,18 @@ __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sq
 
 // One Hermitian pair: zq = Z'[k], zm = Z'[2048-k] (Z' = Z/2), tw = w_4096^k.
 // Returns |X[k]| in ma and |X[2048-k]| in mb.
+// SQ: leave the squares (peak-only mode orders bins by |X|^2 — the square root is monotone — and takes ONE root, of the
+// winner; 32 quarter-rate v_sqrt per lane and frame were 6 % of that mode's issue slots).
+template <bool SQ = false>
 __device__ __forceinline__ void herm_pair(float2 zq, float2 zm, float2 tw, float& ma, float& mb) {
     const float2 e = mk<float>(zq.x + zm.x, zq.y - zm.y);
     const float2 d = mk<float>(zq.x - zm.x, zq.y + zm.y);
     const float2 o = mk<float>(d.y, -d.x);
     const float2 wo = cmul(o, tw);
     const float2 xa = cadd(e, wo), xb = csub(e, wo);
-    ma = fast_sqrt(xa.x * xa.x + xa.y * xa.y);
-    mb = fast_sqrt(xb.x * xb.x + xb.y * xb.y);
+    const float sa_ = xa.x * xa.x + xa.y * xa.y, sb_ = xb.x * xb.x + xb.y * xb.y;
+    ma = SQ ? sa_ : fast_sqrt(sa_);
+    mb = SQ ? sb_ : fast_sqrt(sb_);
 }
 
 
@@ -146,7 +163,11 @@ __device__ __forceinline__ void exch1_pass2(const float2 (&va)[16], const float2
     for (int n2 = 0; n2 < 16; ++n2) c[n2] = slab2[x1_rd + 8 * n2];
     stage_fence();
     bfly16<float>(c);
+#if R4K_TW2_TABLE
+    apply_twiddles16_tab(c, w2p);
+#else
     apply_twiddles16(c, *w2p);
+#endif
     stage_fence();
 }
 
@@ -227,7 +248,12 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
     //    across the frame loop: [0] w_2048^{2t} [1] w_2048^{2t+1} [2] w_128^{t&7} [3] wA [4] wB [5] wC
     //    (Hermitian-pass bases, see below).
     float2* ctab = reinterpret_cast<float2*>(smem_raw + WT_BYTES + WAVES * R4K_SLAB_BYTES);
+    float2* tw2 = ctab + 6 * 64;                                          // [8][17]: w_128^{g k}
     {
+#if R4K_TW2_TABLE
+        static_assert(WAVES * 64 >= 128, "one pass-2 twiddle per thread");
+        if (threadIdx.x < 128) tw2[(threadIdx.x >> 4) * 17 + (threadIdx.x & 15)] = twM[16 * (threadIdx.x >> 4) * (threadIdx.x & 15)];
+#endif
         static_assert(WAVES * 64 <= 1024, "one window quad per thread");
         float2 c[6];
         if (threadIdx.x < 64) {
@@ -313,9 +339,14 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         // ---- exchange 1 + pass 2 (two halves: k1 < 8, k1 >= 8) ----------------------------------
         float2 b0[16], b1[16];
         R4K_STAMP(2);                                   // [2] pass 1
-        exch1_pass2<0>(va, vb, b0, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
+#if R4K_TW2_TABLE
+        const float2* w2p = tw2 + (ln & 7) * 17;
+#else
+        const float2* w2p = ctab + 2 * 64 + ln;
+#endif
+        exch1_pass2<0>(va, vb, b0, slab4, slab2, x1_wr, x1_rd, w2p);
         R4K_STAMP(3);                                   // [3] exchange 1a + pass 2a
-        exch1_pass2<1>(va, vb, b1, slab4, slab2, x1_wr, x1_rd, ctab + 2 * 64 + ln);
+        exch1_pass2<1>(va, vb, b1, slab4, slab2, x1_wr, x1_rd, w2p);
         R4K_STAMP(4);                                   // [4] exchange 1b + pass 2b
         // ---- exchange 2 + pass 3 (two halves: k2 < 8 -> hl < 128, k2 >= 8 -> hl >= 128) ---------
         int l2 = lane;
@@ -349,6 +380,10 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         // o = frame & 3: LDS quad q then maps to the 16-byte ALIGNED global floats 4q - o .. 4q - o + 3.
         const int o = (int)(frame & 3);
         float* slabf = reinterpret_cast<float*>(slab);
+        // Peak only (no spectrum, no metrics): the key carries |Y|^2; the root is taken once, after the wave reduction.
+        // Bins whose squares differ in the last place but whose roots round alike are ordered by the square here and
+        // tie (lowest bin) in the spectrum-writing modes: the two can then name different bins of equal |Y|.
+        constexpr bool SQ = MODE == 0 && FUSE == 0;                   // the fused read-outs stay bit-identical with the kernel chain
         unsigned long long key = 0;                     // (|Y| bits << 32) | (4095 - k): max = peak, lowest k
         // emit |Y[kbase + koff]|: kbase is a per-lane register, koff a compile-time constant
         auto emit = [&](float v, int kbase, int koff) {
@@ -375,10 +410,10 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
             auto slot1 = [&](auto I) {
                 constexpr int i = decltype(I)::value;
                 float ma, mb;
-                herm_pair(U[i], V[7 - i], mul_w16<i>(wA), ma, mb);
+                herm_pair<SQ>(U[i], V[7 - i], mul_w16<i>(wA), ma, mb);
                 emit(ma, kA, 256 * i);                       // k = kA + 256 i ; 2048 - k = kAm + 256 (7 - i)
                 emit(mb, kAm, 256 * (7 - i));
-                herm_pair(U[i + 4], V[3 - i], mul_mi(mul_w16<i>(wB)), ma, mb);
+                herm_pair<SQ>(U[i + 4], V[3 - i], mul_mi(mul_w16<i>(wB)), ma, mb);
                 emit(ma, kB, 256 * i);                       // buffer voffsets must stay non-negative
                 emit(mb, kBm, 256 * (3 - i));
             };
@@ -392,10 +427,10 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
                 constexpr int i = decltype(I)::value;
                 const float2 t = mul_w16<i>(wC);
                 float ma, mb;
-                herm_pair(P2[i], Q2[7 - i], t, ma, mb);
+                herm_pair<SQ>(P2[i], Q2[7 - i], t, ma, mb);
                 emit(ma, kC, 256 * i);
                 emit(mb, kCm, 256 * (7 - i));
-                herm_pair(P2[i + 4], Q2[3 - i], mul_mi(t), ma, mb);
+                herm_pair<SQ>(P2[i + 4], Q2[3 - i], mul_mi(t), ma, mb);
                 emit(ma, kC, 256 * (i + 4));
                 emit(mb, kCm, 256 * (3 - i));
             };
@@ -404,7 +439,8 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         }
         // DC / Nyquist (lane 0 only): X[0] = Re Z0 + Im Z0, X[2048] = Re Z0 - Im Z0, Z0 = 2 z0
         if (special) {
-            const float v0 = fabsf(2.0f * (z0.x + z0.y)), v1 = fabsf(2.0f * (z0.x - z0.y));
+            float v0 = fabsf(2.0f * (z0.x + z0.y)), v1 = fabsf(2.0f * (z0.x - z0.y));
+            if (SQ) { v0 *= v0; v1 *= v1; }
             // Both keys by halves: as 64-bit constants their index words (4095, 2047) were hoisted out of the frame
             // loop as register pairs and spilled.  Bin 0 wins every tie; bin 2048 loses every tie within this lane
             // except against itself (lane 0 emits bins 128 k, all below 2048).
@@ -451,7 +487,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
             const int bk = wave_min_u32(lane_best == best ? lane_bin : 0x7fffffffu);
             if (special) {
                 peak_bin[frame] = bk;
-                peak_mag[frame] = best;
+                peak_mag[frame] = SQ ? fast_sqrt(best) : best;
             }
         }
         R4K_STAMP(8);                                   // [8] peak reduction
