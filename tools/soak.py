@@ -272,7 +272,73 @@ def case_pipeline(rng):
     return desc, None
 
 
-CASES = [(case_pipeline, 0.08), (case_analyze, 0.1), (case_rfft, 0.22), (case_stft, 0.2), (case_c2c, 0.1), (case_anylen, 0.1), (case_compute, 0.2)]
+def case_long(rng):
+    """Frames beyond one LDS pass (rfft_large.hip): 2^15 (fp64) / 2^16 (fp32) .. 2^20."""
+    dtype = np.float32 if rng.random() < 0.5 else np.float64
+    n = 1 << int(rng.integers(16 if dtype == np.float32 else 15, 21))
+    batch = int(rng.integers(1, max(2, (1 << 21) // n)))
+    win = WINDOWS[rng.integers(0, len(WINDOWS))]
+    excl = bool(rng.integers(0, 2))
+    x, kind = make_frames(rng, batch, n, dtype)
+    desc = dict(fn="rfft_long", dtype=str(np.dtype(dtype)), n=n, batch=batch, win=win, excl=excl, kind=kind)
+    mag, pb, pm = fft_amd.rfft_peak(x, window=win, exclude_dc_nyq=excl)
+    mref, pbref, pmref = O.rfft_mag_peak(x, win, 0.0, exclude_dc_nyq=excl)
+    xmax = np.abs(x).max(axis=1).astype(np.float64)
+    live = mref.max(axis=1) > 1e-2 * xmax
+    if live.any() and not peaks_ok(np.asarray(pb)[live], mref[live], pbref[live], excl):
+        return desc, "peak bins differ beyond ties"
+    scale = np.maximum(np.maximum(mref.max(axis=1), 1e-2 * xmax), 1e-300)[:, None]
+    err = (np.abs(mag.astype(np.float64) - mref) / scale).max()
+    if err > (2e-6 if dtype == np.float32 else 1e-12):
+        return desc, f"error {err:.3g} relative to the row maximum"
+    return desc, None
+
+
+def case_dist(rng):
+    """Distributed four-step through P virtual ranks (dist_fft.hip), every exchange mode and layout, vs np.fft.fft."""
+    from fft_amd import dist as D
+    P = int(rng.choice([1, 2, 4, 8, 16]))
+    L = int(rng.integers(max(9 + int(np.log2(P)), 10), 22))
+    ex = str(rng.choice(["fused", "dma", "kernel"]))
+    chunks = int(rng.integers(0, 6))
+    nin, nout = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    n = 1 << L
+    desc = dict(fn="dist_c2c", n=n, P=P, exchange=ex, chunks=chunks, natural_in=nin, natural_out=nout)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 10.0 ** rng.uniform(-3, 3)
+    ref = np.fft.fft(x)
+    with D.DistPlan(n, P, exchange=ex, chunks=chunks, natural_in=nin, natural_out=nout) as plan:
+        plan.scatter(x)
+        st = plan.execute()
+        X = plan.gather()
+    if st["exchanges"] != 1 + nin + nout:
+        return desc, "exchange count"
+    err = np.abs(X - ref).max() / np.abs(ref).max()
+    return desc, (f"error {err:.3g}" if err > 1e-12 else None)
+
+
+def case_shard(rng):
+    """Single-process fan-out over G virtual devices: bytes identical to the unsharded call."""
+    G = int(rng.integers(2, 9))
+    n = 1 << int(rng.integers(6, 14))
+    batch = int(rng.integers(1, 400))
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    win = WINDOWS[rng.integers(0, len(WINDOWS))]
+    x, kind = make_frames(rng, batch, n, dtype)
+    desc = dict(fn="shard_rfft", G=G, n=n, batch=batch, dtype=str(np.dtype(dtype)), win=win, kind=kind)
+    try:
+        fft_amd.set_shard_devices(0)
+        ref = fft_amd.rfft_peak(x, win)
+        fft_amd.set_shard_devices([0] * G)
+        got = fft_amd.rfft_peak(x, win)
+    finally:
+        fft_amd.set_shard_devices(0)
+    for a, b in zip(got, ref):
+        if not np.array_equal(a, b, equal_nan=True):
+            return desc, "sharded result differs from the single call"
+    return desc, None
+
+
+CASES = [(case_long, 0.05), (case_dist, 0.08), (case_shard, 0.05), (case_pipeline, 0.07), (case_analyze, 0.1), (case_rfft, 0.2), (case_stft, 0.15), (case_c2c, 0.08), (case_anylen, 0.08), (case_compute, 0.14)]
 
 
 def main():
