@@ -15,7 +15,9 @@ SA_OK, SA_EINVAL, SA_ENODEV, SA_EHIP, SA_ENOMEM, SA_EUNSUP = 0, -1, -2, -3, -4, 
 
 WIN_NONE, WIN_HANN, WIN_HAMMING, WIN_BLACKMAN, WIN_GAUSSIAN, WIN_NUTTALL = 0, 1, 2, 3, 4, 5
 WINDOW_IDS = {None: 0, "none": 0, "rect": 0, "boxcar": 0, "hann": 1, "hanning": 1, "hamming": 2,
-              "blackman": 3, "gaussian": 4, "gauss": 4, "nuttall": 5}
+              "blackman": 3, "gaussian": 4, "gauss": 4, "nuttall": 5,
+              "fw_hann": 6, "fw_blackman": 7, "fw_nuttall": 8}      # firmware apply_window, win_param = taper percent
+WIN_FW_HANN, WIN_FW_BLACKMAN, WIN_FW_NUTTALL = 6, 7, 8
 F_WRITE_MAG, F_DB, F_EXCLUDE_DC_NYQ = 1, 2, 4
 
 _lib = None

@@ -141,7 +141,7 @@ int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double 
             memcpy(host, w.data(), w.size() * 8);
         };
         char key[96];
-        snprintf(key, sizeof(key), "win64:%d:%.17g:%lld", window, window == SA_WIN_GAUSSIAN ? win_param : 0.0, (long long)n);
+        snprintf(key, sizeof(key), "win64:%d:%.17g:%lld", window, window_has_param(window) && win_param > 0 ? win_param : 0.0, (long long)n);
         dwin = static_cast<const double*>(get_cached_table(key, (size_t)n * 8, fill, &wc));
         if (!dwin) return SA_EHIP;
     }

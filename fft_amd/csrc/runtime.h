@@ -63,6 +63,8 @@ void open_gate();
 
 // Host-side table builders (double precision, exact octant reduction for twiddles).
 void host_window(int window, double win_param, int n, std::vector<double>& w);
+// windows whose table depends on win_param (cache keys carry it only for these)
+inline bool window_has_param(int window) { return window == SA_WIN_GAUSSIAN || (window >= SA_WIN_FW_HANN && window <= SA_WIN_FW_NUTTALL); }
 void host_twiddle(int64_t n, int64_t count, int64_t stride, std::vector<double>& re_im);  // w_n^{stride*i}, i<count
 
 // A device-resident table set for the batched rfft kernels.

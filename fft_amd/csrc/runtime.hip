@@ -251,6 +251,22 @@ void host_window(int window, double win_param, int n, std::vector<double>& w) {
         }
         return;
     }
+    if (window >= SA_WIN_FW_HANN && window <= SA_WIN_FW_NUTTALL) {     // firmware apply_window, Core/Src/main.c:83-99
+        const double taper = win_param > 0 ? win_param : 50.0;
+        if (taper <= 0.1) return;                                       // `taper_pct <= 0.1f` -> all ones
+        const double M = n - 1, edge = taper / 100.0;
+        for (int i = 0; i < n; ++i) {
+            const double a = i / M;
+            double mult = 1.0;
+            if (window == SA_WIN_FW_HANN) mult = 0.5 * (1.0 - cos(2.0 * pi * a));
+            else if (window == SA_WIN_FW_BLACKMAN) mult = 0.42 - 0.5 * cos(2.0 * pi * a) + 0.08 * cos(4.0 * pi * a);
+            else mult = 0.355768 - 0.487396 * cos(2.0 * pi * a) + 0.144232 * cos(4.0 * pi * a) - 0.012604 * cos(6.0 * pi * a);
+            double t = 1.0;
+            if (a < edge) t = a / edge; else if (a > 1.0 - edge) t = (1.0 - a) / edge;
+            w[i] = 1.0 - (1.0 - mult) * t;
+        }
+        return;
+    }
     for (int i = 0; i < n; ++i) {
         // numpy evaluates cos(pi * k / (N-1)) with k = 1-N, 3-N, ..., N-1  (k = 2 i - (N-1))
         const double k = 2.0 * i - (n - 1);
@@ -327,7 +343,7 @@ static int upload(const std::vector<double>& src, void** dptr) {
 const RfftPlan* get_rfft_plan(bool f64, int n, int window, double win_param) {
     int dev = 0;
     hipGetDevice(&dev);
-    if (window != SA_WIN_GAUSSIAN || !(win_param > 0)) win_param = 0;     // <= 0 or NaN: the default std (one plan, not one per call)
+    if (!window_has_param(window) || !(win_param > 0)) win_param = 0;     // <= 0 or NaN: the default (one plan, not one per call)
     PlanKey key(dev, f64, n, window, win_param);
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_plans.find(key);

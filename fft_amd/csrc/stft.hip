@@ -295,7 +295,7 @@ int stft_pcm16_dev(const int16_t* pcm, int64_t n_samples, int32_t channels, int3
         if (window != SA_WIN_NONE) {
             WinF32Ctx wc{window, win_param, nfft};
             char key[96];
-            snprintf(key, sizeof(key), "win32:%d:%.17g:%d", window, window == SA_WIN_GAUSSIAN ? win_param : 0.0, nfft);
+            snprintf(key, sizeof(key), "win32:%d:%.17g:%d", window, window_has_param(window) && win_param > 0 ? win_param : 0.0, nfft);
             a.win = static_cast<const float*>(get_cached_table(key, (size_t)nfft * 4, fill_win32, &wc));
             if (!a.win) return SA_EHIP;
         }

@@ -49,7 +49,15 @@ extern "C" {
                                 win_param <= 0 selects std = (N-1)/5                                */
 #define SA_WIN_NUTTALL   5   /* the firmware's third window (Core/Src/main.c:92): 0.355768 - 0.487396 cos(2 pi a)
                                 + 0.144232 cos(4 pi a) - 0.012604 cos(6 pi a), a = n/(N-1) (symmetric)   */
-#define SA_WIN_LAST      SA_WIN_NUTTALL
+/* The firmware's apply_window as a whole (Core/Src/main.c:83-99): its Hann / Blackman / Nuttall blended towards 1 by the
+ * taper, w[n] = 1 - (1 - mult[n]) t[n], t = a/e for a < e, (1-a)/e for a > 1-e, else 1, with a = n/(N-1), e = taper/100.
+ * win_param = taper percent (the firmware's g_taper_percent, default 50 when win_param <= 0; <= 0.1 % gives all ones as
+ * in the firmware).  Formulas evaluated in fp64 here (the firmware uses float); the reference applies them to a DAC
+ * look-up table, never to an analysed frame — offered for completeness of a11. */
+#define SA_WIN_FW_HANN      6
+#define SA_WIN_FW_BLACKMAN  7
+#define SA_WIN_FW_NUTTALL   8
+#define SA_WIN_LAST      SA_WIN_FW_NUTTALL
 
 /* ---- flags -------------------------------------------------------------------------------- */
 #define SA_F_WRITE_MAG       1   /* write the N/2+1 magnitudes per frame (else peak only)          */

@@ -229,7 +229,8 @@ def dominant_peak(f, Y, positive_only=False):
 # ---- a11: windows (numpy / scipy symmetric definitions; firmware Core/Src/main.c:83-99 agrees) ------
 def window(kind, n, param=0.0):
     kind = (kind or "none").lower() if not isinstance(kind, int) else kind
-    names = {0: "none", 1: "hann", 2: "hamming", 3: "blackman", 4: "gaussian", 5: "nuttall"}
+    names = {0: "none", 1: "hann", 2: "hamming", 3: "blackman", 4: "gaussian", 5: "nuttall", 6: "fw_hann", 7: "fw_blackman",
+             8: "fw_nuttall"}
     kind = names.get(kind, kind)
     if kind in ("none", "rect", "boxcar"):
         return np.ones(n)
@@ -250,6 +251,31 @@ def window(kind, n, param=0.0):
         a = np.arange(n) / (n - 1.0)
         return (0.355768 - 0.487396 * np.cos(2 * np.pi * a) + 0.144232 * np.cos(4 * np.pi * a)
                 - 0.012604 * np.cos(6 * np.pi * a))
+    if kind in ("fw_hann", "fw_blackman", "fw_nuttall"):
+        # the firmware's apply_window as a whole (Core/Src/main.c:83-99), param = taper percent (g_taper_percent, 50);
+        # it evaluates in float, this is the same statement sequence in fp64.  Parity unpinned: the firmware cannot run here.
+        taper = param if param and param > 0 else 50.0
+        w = np.ones(n)
+        if taper <= 0.1:
+            return w
+        M = float(n - 1)
+        edge = taper / 100.0
+        for i in range(n):
+            a = i / M
+            if kind == "fw_hann":
+                mult = 0.5 * (1.0 - np.cos(2.0 * np.pi * a))
+            elif kind == "fw_blackman":
+                mult = 0.42 - 0.5 * np.cos(2.0 * np.pi * a) + 0.08 * np.cos(4.0 * np.pi * a)
+            else:
+                mult = (0.355768 - 0.487396 * np.cos(2.0 * np.pi * a) + 0.144232 * np.cos(4.0 * np.pi * a)
+                        - 0.012604 * np.cos(6.0 * np.pi * a))
+            t = 1.0
+            if a < edge:
+                t = a / edge
+            elif a > (1.0 - edge):
+                t = (1.0 - a) / edge
+            w[i] = 1.0 - (1.0 - mult) * t
+        return w
     raise ValueError(kind)
 
 

@@ -166,6 +166,27 @@ def test_db_mode_matches_oracle_every_kernel_family(n):
     assert np.abs(magdb[live] - 20 * np.log10(np.maximum(mag[live].astype(np.float64), 1e-30))).max() < 2e-4
 
 
+@pytest.mark.parametrize("win,taper", [("fw_hann", 0.0), ("fw_blackman", 30.0), ("fw_nuttall", 50.0), ("fw_hann", 80.0), ("fw_hann", 0.05)])
+def test_firmware_taper_windows(win, taper):
+    """a11: the firmware's apply_window as a whole (Core/Src/main.c:83-99), taper blend included.  taper 80 % makes the
+    table asymmetric (its two ramps overlap and the left one wins, as in the C code): the 4096-point kernel must then
+    take its full-table form; 0.05 % is the firmware's "all ones" branch."""
+    import fft_amd
+    rng = np.random.default_rng(int(taper * 10) + len(win))
+    for n, dtype, tol in ((4096, np.float32, 1e-5 * 12), (1024, np.float64, 1e-12), (1 << 16, np.float32, 2e-6)):
+        x = (np.sin(2 * np.pi * 0.1234 * np.arange(n)) + 0.1 * rng.standard_normal((7, n))).astype(dtype)
+        mag, pb, pm = fft_amd.rfft_peak(x, win, win_param=taper)
+        mref, pbref, _ = O.rfft_mag_peak(x, win, taper)
+        assert rel_l2(mag, mref).max() < tol, (n, win, taper)
+        check_peaks(pb, pm, mref, pbref)
+    w = O.window(win, 257, taper)
+    if 0.1 < (taper or 50.0) <= 50.0:
+        np.testing.assert_allclose(w, w[::-1], atol=1e-15)             # symmetric while the ramps do not overlap
+    assert w[0] == 1.0                                                  # t = 0 at the edge: no attenuation there
+    if taper == 0.05:
+        assert (w == 1.0).all()
+
+
 def test_kats_impulse_dc_nyquist_ties():
     import fft_amd
     n = 4096
