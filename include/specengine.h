@@ -110,9 +110,9 @@ int sa_shard_count(void);
  *   peak_bin  [batch]           argmax_k |Y[k]|, lowest k on ties (np.argmax semantics)
  *   peak_mag  [batch]           |Y[peak_bin]| (always linear)
  * n: power of two >= 16.  n <= 32768 (f32) / 16384 (f64) run in ONE LDS-resident pass.  Longer frames, up to 2^29
- *    (the late forks transform up to 1 000 000 points, sab10.py:43, 644), take the multi-pass path: n/2-point complex
- *    transform on the fp64 engine + Hermitian unpack with |Y| and the peak fused; it computes in fp64 whatever the frame
- *    type, borrows its work buffers from the library, and the *_dev forms then synchronise `stream` before returning.
+ *    (the late forks transform up to 1 000 000 points, sab10.py:43, 644), take the multi-pass path: a real-input
+ *    four-step in the frame's own arithmetic (window fused into the first pass, |Y| / dB / peak into the last); it
+ *    borrows one work buffer from the library, and the *_dev forms then synchronise `stream` before returning.
  *    Other n are served by sa_fft_mag_f64 (any n).                                               */
 int sa_rfft_peak_f32(const float* x, int64_t batch, int32_t n, int32_t window, double win_param,
                      int32_t flags, float* mag, int32_t* peak_bin, float* peak_mag);

@@ -61,8 +61,8 @@ def test_rfft_f64_all_sizes(n, win):
 @pytest.mark.parametrize("win", ["none", "hann", "gaussian"])
 def test_rfft_long_frames_multi_pass(dtype, log2n, batch, win):
     """Frames longer than one LDS-resident pass (the late forks reach 1 000 000 points, sab10.py:43, 644): n/2-point
-    complex transform on the multi-pass engine + Hermitian unpack (rfft_large.hip).  Same bars as the short frames:
-    fp32 1e-5 log2 N relative L2 (the path computes in fp64, so it sits at fp32 output rounding), fp64 1e-12."""
+    real-column four-step in the frame's own arithmetic (rfft_large.hip).  Same bars as the short frames: fp32
+    1e-5 log2 N relative L2 (measured: < 1e-6 up to 2^22), fp64 1e-12."""
     import fft_amd
     n = 1 << log2n
     rng = np.random.default_rng(log2n * 3 + len(win))
@@ -74,9 +74,9 @@ def test_rfft_long_frames_multi_pass(dtype, log2n, batch, win):
     assert mag.dtype == dtype and mag.shape == (batch, n // 2 + 1)
     if dtype == np.float32:
         assert rel_l2(mag, mref).max() < 1e-5 * log2n
-        assert rel_l2(mag, mref).max() < 2e-7                 # in fact: fp64 arithmetic, fp32 rounding of the outputs
+        assert rel_l2(mag, mref).max() < 1e-6
         check_peaks(pb, pm, mref, pbref)
-        np.testing.assert_allclose(pm, pmref, rtol=1e-6)
+        np.testing.assert_allclose(pm, pmref, rtol=1e-5)
     else:
         assert (np.abs(mag - mref).max(axis=1) / mref.max(axis=1)).max() < 1e-12
         np.testing.assert_array_equal(pb, pbref)
@@ -86,7 +86,13 @@ def test_rfft_long_frames_multi_pass(dtype, log2n, batch, win):
     if win == "hann":
         magdb, pb2, pm2 = fft_amd.rfft_peak(x, win, db=True, exclude_dc_nyq=True)
         mrefdb, pbref2, _ = O.rfft_mag_peak(x, win, db=True, exclude_dc_nyq=True)
-        assert np.abs(magdb - mrefdb)[:, 1:-1].max() < (1e-3 if dtype == np.float32 else 1e-9)
+        if dtype == np.float32:                         # bins clear of the frame's fp32 rounding residue (see the dB test below)
+            sel = mref > 0.05 * mref.max(axis=1, keepdims=True)
+            assert sel.sum() >= batch and np.abs(magdb - mrefdb)[sel].max() < 1e-3
+            live = mag > 0
+            assert np.abs(magdb[live] - 20 * np.log10(mag[live].astype(np.float64))).max() < 2e-4
+        else:
+            assert np.abs(magdb - mrefdb)[:, 1:-1].max() < 1e-9
         np.testing.assert_array_equal(pb2, pb)
         none_, pb3, pm3 = fft_amd.rfft_peak(x, win, write_mag=False)
         assert none_ is None

@@ -167,6 +167,10 @@ if __name__ == "__main__":
         for dtype in ("f32", "f64"):
             for lg in range(6, 15):
                 results.append(bench_rfft(1 << lg, dtype)); print(json.dumps(results[-1]), flush=True)
+    if "long" in which:                                  # frames beyond one LDS pass (rfft_large.hip), 2^28 samples per launch
+        for dtype in ("f32", "f64"):
+            for lg in (16, 18, 20, 22):
+                results.append(bench_rfft(1 << lg, dtype, 28)); print(json.dumps(results[-1]), flush=True)
     if "metrics" in which:
         results.append(bench_metrics()); print(json.dumps(results[-1]), flush=True)
     if "analyze" in which:

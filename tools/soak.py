@@ -273,10 +273,10 @@ def case_pipeline(rng):
 
 
 def case_long(rng):
-    """Frames beyond one LDS pass (rfft_large.hip): 2^15 (fp64) / 2^16 (fp32) .. 2^20."""
+    """Frames beyond one LDS pass (rfft_large.hip): 2^15 (fp64) / 2^16 (fp32) .. 2^22."""
     dtype = np.float32 if rng.random() < 0.5 else np.float64
-    n = 1 << int(rng.integers(16 if dtype == np.float32 else 15, 21))
-    batch = int(rng.integers(1, max(2, (1 << 21) // n)))
+    n = 1 << int(rng.integers(16 if dtype == np.float32 else 15, 23))
+    batch = int(rng.integers(1, max(2, (1 << 22) // n)))
     win = WINDOWS[rng.integers(0, len(WINDOWS))]
     excl = bool(rng.integers(0, 2))
     x, kind = make_frames(rng, batch, n, dtype)
