@@ -503,34 +503,70 @@ int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double 
     a.R2 = l3 ? 1LL << l2 : 1; a.R3 = 1LL << lf;
     const int64_t ncand = a.R2 * (a.R1 / 2 + 1);           // one per kept (row, k2)
     const int64_t wframe = (a.R1 / 2 + 1) * a.S1 * (int64_t)sizeof(cplx<T>);
-    // frames per chunk: the work buffer stays inside the thread's cached arena (and inside the 256 MiB MALL, so that the
-    // passes hand the intermediate to each other without a round trip to HBM); SA_RL_CHUNK_MIB tunes it
-    static const int64_t chunk_mib = getenv("SA_RL_CHUNK_MIB") ? atoll(getenv("SA_RL_CHUNK_MIB")) : 128;
+    // Frames go through in chunks, `lanes` chunks in flight at a time, each lane on a stream of its own with its own work
+    // buffer: one chunk's kernels fill the ramp-up / tail / launch gaps of the other's, and a chunk small enough that
+    // frames + intermediate + spectra of all lanes stay inside the 256 MiB MALL hands its intermediate from pass to pass
+    // without a round trip to HBM.  SA_RL_CHUNK_MIB / SA_RL_LANES tune it; measured (ms per 2^28 fp32 samples, 2^16 / 2^18 /
+    // 2^21): 1 lane x 128 MiB 1.05 / 1.26 / 1.55, 2 x 64 MiB 0.98 / 1.20 / 1.46, 3 x 64 1.07 / 1.24 / 1.52, 2 x 32 1.08 / 1.33 / 1.70.
+    static const int64_t chunk_mib = getenv("SA_RL_CHUNK_MIB") ? atoll(getenv("SA_RL_CHUNK_MIB")) : 64;
+    static const int lanes_env = getenv("SA_RL_LANES") ? atoi(getenv("SA_RL_LANES")) : 2;
     int64_t chunk = (chunk_mib << 20) / wframe;
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
+    int lanes = lanes_env < 1 ? 1 : lanes_env > 4 ? 4 : lanes_env;
+    if ((int64_t)lanes > (batch + chunk - 1) / chunk) lanes = (int)((batch + chunk - 1) / chunk);
     Temp tmp;
-    a.work = static_cast<cplx<T>*>(tmp.dev((size_t)chunk * wframe));
-    a.cand = static_cast<RlCand*>(tmp.dev((size_t)chunk * ncand * sizeof(RlCand)));
-    int rc = (!a.work || !a.cand) ? SA_ENOMEM : SA_OK;
-    for (int64_t b0 = 0; rc == SA_OK && b0 < batch; b0 += chunk) {
+    cplx<T>* work[4] = {};
+    RlCand* cand[4] = {};
+    hipStream_t ls[4] = {st, nullptr, nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_done[4] = {};
+    int rc = SA_OK;
+    for (int l = 0; l < lanes && rc == SA_OK; ++l) {
+        work[l] = static_cast<cplx<T>*>(tmp.dev((size_t)chunk * wframe));
+        cand[l] = static_cast<RlCand*>(tmp.dev((size_t)chunk * ncand * sizeof(RlCand)));
+        if (!work[l] || !cand[l]) rc = SA_ENOMEM;
+        if (l > 0 && rc == SA_OK) {
+            ls[l] = thread_aux_stream(l - 1);
+            if (!ls[l] || hipEventCreateWithFlags(&ev_done[l], hipEventDisableTiming) != hipSuccess) { set_error("rfft multi-pass path: no auxiliary stream / event"); rc = SA_EHIP; }
+        }
+    }
+    if (rc == SA_OK && lanes > 1) {                        // the lanes start after whatever the caller queued on `st` before this call
+        if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev_in, st) != hipSuccess) { set_error("rfft multi-pass path: event"); rc = SA_EHIP; }
+        for (int l = 1; l < lanes && rc == SA_OK; ++l)
+            if (hipStreamWaitEvent(ls[l], ev_in, 0) != hipSuccess) { set_error("rfft multi-pass path: stream wait"); rc = SA_EHIP; }
+    }
+    int64_t ci = 0;
+    for (int64_t b0 = 0; rc == SA_OK && b0 < batch; b0 += chunk, ++ci) {
+        const int l = (int)(ci % lanes);
+        hipStream_t s = ls[l];
+        a.work = work[l]; a.cand = cand[l];
         a.batch = batch - b0 < chunk ? batch - b0 : chunk;
         a.x = x + b0 * n;
         a.mag = (flags & SA_F_WRITE_MAG) && mag ? mag + b0 * ((int64_t)n / 2 + 1) : nullptr;
         if ((rc = rl_set_twiddles(a, l1, n)) != SA_OK) break;
-        if ((rc = rl_dispatch<T>(0, l1, a, st)) != SA_OK) break;
+        if ((rc = rl_dispatch<T>(0, l1, a, s)) != SA_OK) break;
         if (l3) {
             if ((rc = rl_set_twiddles(a, l2, a.S1)) != SA_OK) break;
-            if ((rc = rl_dispatch<T>(1, l2, a, st)) != SA_OK) break;
+            if ((rc = rl_dispatch<T>(1, l2, a, s)) != SA_OK) break;
         }
         if ((rc = rl_set_twiddles(a, lf, 0)) != SA_OK) break;
-        if ((rc = rl_dispatch<T>(2, lf, a, st)) != SA_OK) break;
-        hipLaunchKernelGGL(rl_peak_kernel<T>, dim3((unsigned)a.batch), dim3(1024), 0, st, a.cand, ncand, peak_bin + b0, peak_mag + b0);
+        if ((rc = rl_dispatch<T>(2, lf, a, s)) != SA_OK) break;
+        hipLaunchKernelGGL(rl_peak_kernel<T>, dim3((unsigned)a.batch), dim3(1024), 0, s, a.cand, ncand, peak_bin + b0, peak_mag + b0);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("rfft multi-pass kernels: %s", hipGetErrorString(e)); rc = SA_EHIP; }
     }
-    const hipError_t e = hipStreamSynchronize(st);       // the arena goes back with nothing in flight
+    // the arena goes back with nothing in flight: every lane is drained, and `st` is ordered after all of them
+    for (int l = 1; l < lanes; ++l) {
+        if (!ls[l]) continue;
+        if (ev_done[l] && hipEventRecord(ev_done[l], ls[l]) == hipSuccess) (void)hipStreamWaitEvent(st, ev_done[l], 0);
+        const hipError_t e = hipStreamSynchronize(ls[l]);
+        if (rc == SA_OK && e != hipSuccess) { set_error("rfft multi-pass path: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+    }
+    const hipError_t e = hipStreamSynchronize(st);
     if (rc == SA_OK && e != hipSuccess) { set_error("rfft multi-pass path: %s", hipGetErrorString(e)); rc = SA_EHIP; }
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    for (int l = 1; l < 4; ++l)
+        if (ev_done[l]) (void)hipEventDestroy(ev_done[l]);
     return rc;
 }
 template int rfft_large_dev<float>(const float*, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);

@@ -19,6 +19,7 @@ bool initialised();                // ensure_init has succeeded in this process
 // (once per device; returns it in *out when out != nullptr)
 int noalloc_setup_current_device(uint8_t** out);
 hipStream_t thread_stream();       // the calling thread's library stream on the current device
+hipStream_t thread_aux_stream(int i);  // i < 15: further streams of the calling thread on the current device (overlapped lanes)
 int num_cus();                     // multiprocessor count of the current device
 // Raise a kernel's dynamic-LDS limit on the current device once (the attribute is per device, and a thread may
 // move between devices with sa_set_device); `devs` is the caller's per-kernel bitmask of devices already done.

@@ -124,17 +124,20 @@ struct ThreadCacheHolder {
 };
 static thread_local ThreadCacheHolder t_cache;
 
-hipStream_t thread_stream() {
+static hipStream_t thread_stream_slot(int slot) {     // slot 0: the library stream; 1 ..: auxiliary lanes
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::map<int, hipStream_t>& m = t_cache.c->streams;
-    auto it = m.find(dev);
+    const int key = dev * 16 + slot;
+    auto it = m.find(key);
     if (it != m.end()) return it->second;
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    m[dev] = st;
+    m[key] = st;
     return st;
 }
+hipStream_t thread_stream() { return thread_stream_slot(0); }
+hipStream_t thread_aux_stream(int i) { return (i < 0 || i >= 15) ? nullptr : thread_stream_slot(1 + i); }
 
 int allow_dynamic_lds(const void* kernel, int bytes, uint64_t* devs) {
     int dev = 0;
