@@ -84,8 +84,8 @@ PROTOTYPES = {
 
 DIST_MAX_RANKS = 16
 DIST_NATURAL_IN, DIST_NATURAL_OUT = 1, 2
-DIST_XCHG_AUTO, DIST_XCHG_DMA, DIST_XCHG_KERNEL, DIST_XCHG_FUSED = 0, 1, 2, 3
-DIST_XCHG_NAMES = {"auto": 0, "dma": 1, "kernel": 2, "fused": 3}
+DIST_XCHG_AUTO, DIST_XCHG_DMA, DIST_XCHG_KERNEL, DIST_XCHG_FUSED, DIST_XCHG_RCCL = 0, 1, 2, 3, 4
+DIST_XCHG_NAMES = {"auto": 0, "dma": 1, "kernel": 2, "fused": 3, "rccl": 4}
 DIST_KAT_IMPULSE, DIST_KAT_TONE, DIST_KAT_NOISE = 0, 1, 2
 
 

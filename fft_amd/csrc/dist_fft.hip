@@ -17,11 +17,18 @@
 //   DMA     pass 1 writes a send buffer; one hipMemcpyAsync per (source, owner, chunk) on a stream per pair
 //   KERNEL  same, copies done by a copy kernel on the source device storing through the peer mapping
 //   FUSED   pass 1's store epilogue writes straight into the owners' receive buffers: no send buffer, no copy pass
+//   RCCL    pass 1 writes a send buffer; per chunk one RCCL group over all ranks' communicators: ncclAllToAll when the
+//           exchange is a single chunk, grouped ncclSend / ncclRecv per (source, owner) otherwise.  One
+//           communicator per rank from ncclCommInitAll, so every rank needs a device of its own (RCCL refuses two ranks on
+//           one device).  librccl is loaded with dlopen when this mode is first asked for: no link-time dependency.
 // DMA / KERNEL deliver the rows in chunks and an owner starts the transforms of a chunk as soon as all P parts of it
 // have arrived, so the rest of the exchange overlaps them.  The receive layout is always "one block per
 // source": recv[p][k1l][sl]; phase 2's first pass reads it in place (blocked loads), nothing is unpacked.
 #include <chrono>
+#include <dlfcn.h>
 #include <string.h>
+
+#include <rccl/rccl.h>       // types and prototypes only; the entry points are resolved with dlsym
 
 #include <vector>
 
@@ -35,6 +42,40 @@ int dist_phase2(const double* in_blocked, double* work, double* out, int64_t S, 
                 int nt, hipStream_t st);
 
 using Cd = double2;
+
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllToAll) AllToAll = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+static const RcclApi* rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+        a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(a.lib, "ncclCommInitAll"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
+        a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(a.lib, "ncclSend"));
+        a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(a.lib, "ncclRecv"));
+        a.AllToAll = reinterpret_cast<decltype(a.AllToAll)>(dlsym(a.lib, "ncclAllToAll"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        a.ok = a.CommInitAll && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.AllToAll && a.GetErrorString;
+        return a;
+    }();
+    return api.ok ? &api : nullptr;
+}
 
 // dst[r * dpitch + c] = src[r * spitch + c]  (16-byte elements; rows are long, so a flat grid-stride loop coalesces)
 __global__ void __launch_bounds__(256) dist_copy2d_kernel(Cd* __restrict__ dst, int64_t dpitch, const Cd* __restrict__ src,
@@ -151,6 +192,7 @@ struct sa_dist_plan {
     int P = 0, L = 0, l1 = 0, J = 1, mode = 0, flags = 0, nt = 0, n_devices = 0;
     bool nat_in = false, nat_out = false;
     std::vector<sa_dist_rank> r;
+    std::vector<ncclComm_t> comms;                       // RCCL mode: one communicator per rank (ncclCommInitAll)
 };
 
 namespace sa {
@@ -169,6 +211,15 @@ namespace sa {
         rc = (expr);                      \
         if (rc != SA_OK) goto done;       \
     } while (0)
+#define SA_NCCLD(call)                                                                                            \
+    do {                                                                                                          \
+        ncclResult_t n_ = (call);                                                                                 \
+        if (n_ != ncclSuccess) {                                                                                  \
+            set_error("%s failed: %s (%s:%d)", #call, rccl_api()->GetErrorString(n_), __FILE__, __LINE__);        \
+            rc = SA_EHIP;                                                                                         \
+            goto done;                                                                                            \
+        }                                                                                                         \
+    } while (0)
 
 struct DeviceRestore {
     int dev = 0;
@@ -179,6 +230,13 @@ struct DeviceRestore {
 static void dist_free(sa_dist_plan* p) {
     if (!p) return;
     DeviceRestore keep;
+    for (size_t i = 0; i < p->comms.size(); ++i)
+        if (p->comms[i]) {
+            (void)hipSetDevice(p->r[i].dev);
+            if (p->r[i].compute) (void)hipStreamSynchronize(p->r[i].compute);
+            for (hipStream_t s : p->r[i].copy) if (s) (void)hipStreamSynchronize(s);
+            (void)rccl_api()->CommDestroy(p->comms[i]);
+        }
     for (sa_dist_rank& k : p->r) {
         (void)hipSetDevice(k.dev);
         if (k.compute) (void)hipStreamSynchronize(k.compute);
@@ -224,7 +282,7 @@ int sa_dist_plan_create(sa_dist_plan** plan_out, int64_t n, int32_t n_ranks, con
     }
     if (n < 2 || (1LL << L) != n || L > 30) { set_error("dist c2c: n=%lld must be a power of two <= 2^30", (long long)n); return SA_EUNSUP; }
     const int mode_req = (flags >> 4) & 15, chunks_req = (flags >> 8) & 255;
-    if ((flags & ~0xFFF3) || mode_req > SA_DIST_XCHG_FUSED) { set_error("dist c2c: unknown flag bits 0x%x", flags); return SA_EINVAL; }
+    if ((flags & ~0xFFF3) || mode_req > SA_DIST_XCHG_RCCL) { set_error("dist c2c: unknown flag bits 0x%x", flags); return SA_EINVAL; }
     // first factor: 2^6 .. 2^10, at least one row per rank, leaving rows of >= 2^13 points where n allows (so the owners'
     // first pass is the blocked strided pass at every size worth measuring) and columns per rank in groups of 8
     int l1 = L - 14;
@@ -255,6 +313,20 @@ int sa_dist_plan_create(sa_dist_plan** plan_out, int64_t n, int32_t n_ranks, con
     }
     p->n_devices = (int)devs.size();
     p->mode = mode_req ? mode_req : (one_device ? SA_DIST_XCHG_FUSED : SA_DIST_XCHG_DMA);
+    if (p->mode == SA_DIST_XCHG_RCCL) {
+        if (p->n_devices != n_ranks) {
+            set_error("dist c2c: the RCCL exchange needs one device per rank (%d ranks on %d device(s)); RCCL refuses two ranks "
+                      "on one device - use DMA, KERNEL or FUSED for virtual ranks", n_ranks, p->n_devices);
+            delete p;
+            return SA_EUNSUP;
+        }
+        if (!rccl_api()) {
+            const char* why = dlerror();
+            set_error("dist c2c: librccl.so could not be loaded (%s)", why ? why : "missing symbols");
+            delete p;
+            return SA_EUNSUP;
+        }
+    }
     int J = chunks_req ? chunks_req : 4;
     if (p->mode == SA_DIST_XCHG_FUSED) J = 1;
     while (J > 1 && (p->K1L % J || p->K1L / J < 1)) --J;
@@ -297,6 +369,12 @@ int sa_dist_plan_create(sa_dist_plan** plan_out, int64_t n, int32_t n_ranks, con
         k.e_chunk.assign(n_ranks, std::vector<hipEvent_t>(J, nullptr));
         for (int q = 0; q < n_ranks; ++q)
             for (int j = 0; j < J; ++j) SA_HIPD(hipEventCreate(&k.e_chunk[q][j]));
+    }
+    if (p->mode == SA_DIST_XCHG_RCCL) {
+        std::vector<int> devlist(n_ranks);
+        for (int i = 0; i < n_ranks; ++i) devlist[i] = p->r[i].dev;
+        p->comms.assign(n_ranks, nullptr);
+        SA_NCCLD(rccl_api()->CommInitAll(p->comms.data(), n_ranks, devlist.data()));
     }
     for (int i = 0; i < n_ranks; ++i) {                      // push table of source i: owner q's block for source i
         std::vector<double*> tab(n_ranks);
@@ -420,7 +498,46 @@ int sa_dist_execute(sa_dist_plan* p, sa_dist_stats* stats) {
         SA_HIPD(hipEventRecord(k.e_p1e, k.compute));
     }
     // --- the exchange: (source i, owner q, chunk j) = rows [q K1L + j CH, + CH) of i's send buffer -> block i of q's recv
-    if (p->mode != SA_DIST_XCHG_FUSED) {
+    if (p->mode == SA_DIST_XCHG_RCCL) {
+        // one RCCL group per chunk over every rank's communicator, on the rank's stream copy[0]; the chunk has arrived at
+        // owner q when q's own stream passes the event recorded after the group (its receives are ordered before it)
+        const RcclApi* nc = rccl_api();
+        for (int j = 0; j < J; ++j) {
+            for (int i = 0; i < P; ++i) {
+                sa_dist_rank& k = p->r[i];
+                if (j == 0) {
+                    SA_HIPD(hipSetDevice(k.dev));
+                    SA_HIPD(hipStreamWaitEvent(k.copy[0], k.e_p1e, 0));
+                    for (int q = 0; q < P; ++q) SA_HIPD(hipEventRecord(k.e_cs[q], k.copy[0]));
+                }
+            }
+            SA_NCCLD(nc->GroupStart());
+            for (int i = 0; i < P; ++i) {
+                sa_dist_rank& k = p->r[i];
+                if (J == 1) {                                // blocks of blk points at stride blk on both sides: the all-to-all itself
+                    ncclResult_t r_ = nc->AllToAll(k.send, k.recv, (size_t)blk * 2, ncclDouble, p->comms[i], k.copy[0]);
+                    if (r_ != ncclSuccess) { (void)nc->GroupEnd(); SA_NCCLD(r_); }
+                    continue;
+                }
+                for (int dq = 0; dq < P; ++dq) {
+                    const int q = (i + dq) % P;
+                    ncclResult_t r_ = nc->Send(k.send + 2 * (((int64_t)q * K1L + (int64_t)j * CH) * Sp), (size_t)CH * Sp * 2, ncclDouble, q, p->comms[i], k.copy[0]);
+                    if (r_ == ncclSuccess)
+                        r_ = nc->Recv(k.recv + 2 * (((int64_t)q * K1L + (int64_t)j * CH) * Sp), (size_t)CH * Sp * 2, ncclDouble, q, p->comms[i], k.copy[0]);
+                    if (r_ != ncclSuccess) { (void)nc->GroupEnd(); SA_NCCLD(r_); }
+                }
+            }
+            SA_NCCLD(nc->GroupEnd());
+            for (int i = 0; i < P; ++i) {
+                sa_dist_rank& k = p->r[i];
+                SA_HIPD(hipSetDevice(k.dev));
+                for (int q = 0; q < P; ++q) {
+                    SA_HIPD(hipEventRecord(k.e_chunk[q][j], k.copy[0]));
+                    if (j == J - 1) SA_HIPD(hipEventRecord(k.e_ce[q], k.copy[0]));
+                }
+            }
+        }
+    } else if (p->mode != SA_DIST_XCHG_FUSED) {
         for (int j = 0; j < J; ++j)
             for (int i = 0; i < P; ++i) {
                 sa_dist_rank& k = p->r[i];

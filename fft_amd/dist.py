@@ -92,7 +92,7 @@ class DistPlan:
 
     devices: rank -> HIP device (None: rank i on device i % device_count).  Several ranks may share a device
     ("virtual ranks"), which is how the whole path is tested on a one-GPU machine.
-    exchange: "auto" | "dma" | "kernel" | "fused";  chunks: row chunks the exchange is delivered in (DMA / kernel).
+    exchange: "auto" | "dma" | "kernel" | "fused" | "rccl" (one device per rank);  chunks: row chunks the exchange is delivered in (DMA / kernel).
     natural_in / natural_out: contiguous slabs x[r n/P ...] / X[q n/P ...] instead of column / row blocks, one more
     all-to-all each.  Layouts: see include/specengine.h (sa_dist_plan_create) and the helpers below."""
 

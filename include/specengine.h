@@ -162,8 +162,10 @@ int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_
  *   SA_DIST_NATURAL_IN / _OUT: contiguous slabs x[r n/P ...] / X[q n/P ...] instead, one more all-to-all each.
  * Exchange: SA_DIST_XCHG(mode) — DMA = one hipMemcpyAsync per (source, owner, chunk); KERNEL = the same copies by a
  * copy kernel storing through the peer mapping; FUSED = the first pass' store epilogue writes straight into the owners'
- * receive buffers (no send buffer, no copy pass); AUTO = FUSED when every rank shares one device, else DMA.
- * DMA / KERNEL deliver in SA_DIST_CHUNKS(j) row chunks (default 4) and an owner transforms a chunk while the rest is
+ * receive buffers (no send buffer, no copy pass); RCCL = ncclAllToAll (one chunk) or grouped ncclSend / ncclRecv per chunk
+ * over one communicator per rank (needs a device of its own per rank: SA_EUNSUP otherwise, or when librccl.so cannot be
+ * loaded); AUTO = FUSED when every rank shares one device, else DMA.
+ * DMA / KERNEL / RCCL deliver in SA_DIST_CHUNKS(j) row chunks (default 4) and an owner transforms a chunk while the rest is
  * still on the wire.  sa_dist_execute is synchronous (returns when every rank is done) and fills `stats` if given. */
 #define SA_DIST_MAX_RANKS    16
 #define SA_DIST_NATURAL_IN   1
@@ -172,6 +174,7 @@ int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_
 #define SA_DIST_XCHG_DMA     1
 #define SA_DIST_XCHG_KERNEL  2
 #define SA_DIST_XCHG_FUSED   3
+#define SA_DIST_XCHG_RCCL    4
 #define SA_DIST_XCHG(mode)   ((mode) << 4)
 #define SA_DIST_CHUNKS(j)    ((j) << 8)
 typedef struct sa_dist_plan sa_dist_plan;

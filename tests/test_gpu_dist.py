@@ -68,6 +68,40 @@ def test_dist_natural_order_both_sides(P, exchange):
     assert np.abs(X - np.fft.fft(x)).max() / np.sqrt(n) < 1e-11
 
 
+@pytest.mark.parametrize("chunks", [1, 4])
+def test_dist_rccl_exchange_one_rank_per_device(chunks):
+    """The RCCL exchange (north_star: "RCCL all-to-all"): ncclAllToAll for a single chunk, grouped ncclSend / ncclRecv per
+    chunk otherwise, one communicator per rank from ncclCommInitAll.  RCCL refuses two ranks on one device, so this runs
+    with as many ranks as the box has devices (a power of two): on the one-GPU box that is P = 1 — the self exchange
+    still goes through librccl's kernels on the GPU; the multi-rank form has never run.  Virtual ranks are
+    refused with a message that says why."""
+    import torch
+    ndev = torch.cuda.device_count()
+    P = 1
+    while P * 2 <= min(ndev, 8):
+        P *= 2
+    for L in (13, 20):
+        n = 1 << L
+        x = _rand(n, L + 7 * chunks)
+        ref = np.fft.fft(x)
+        with D.DistPlan(n, P, devices=list(range(P)), exchange="rccl", chunks=chunks) as plan:
+            assert plan.exchange == "rccl"
+            plan.scatter(x)
+            st = plan.execute()
+            assert st["exchange_mode"] == "rccl" and st["n_chunks"] == min(chunks, plan.rows_per_rank) and st["exchanges"] == 1
+            X = plan.gather()
+            assert np.abs(X - ref).max() / np.abs(ref).max() < 1e-12, (L, P, chunks)
+            with D.DistPlan(n, P, devices=list(range(P)), exchange="dma", chunks=chunks) as other:
+                other.scatter(x)
+                other.execute()
+                np.testing.assert_array_equal(other.gather(), X)          # same bits as the peer-copy exchange
+    lib = _lib.load()
+    import ctypes as C
+    h = C.c_void_p()
+    rc = lib.sa_dist_plan_create(C.byref(h), 1 << 16, 2, (C.c_int32 * 2)(0, 0), _lib.DIST_XCHG_RCCL << 4)
+    assert rc == _lib.SA_EUNSUP and "one device per rank" in _lib.last_error()
+
+
 def test_dist_2_24_vs_numpy():
     n = 1 << 24
     x = _rand(n, 24)

@@ -3,7 +3,8 @@
 libspecengine (csrc/dist_fft.hip) — ONE process drives every rank; ranks map to the visible devices round-robin, so
 `--ranks 8` uses 8 GPUs where there are 8 and 8 virtual ranks on one GPU where there is one.
 
-    python tools/bench_dist_c5.py --log2n 30 --ranks 1,2,4,8 --exchange fused,dma,kernel
+    python tools/bench_dist_c5.py --log2n 30 --ranks 1,2,4,8 --exchange fused,dma,kernel,rccl
+(the RCCL exchange needs a device per rank: it is skipped, with a note, for rank counts above the device count)
 
 Input: the analytic tone e^{2 pi i k0 j / n} (k0 = 987 654 321 mod n) generated on the devices; check: X[k0] = n and
 everything else ~ 0, evaluated on the devices.  One JSON line per (ranks, exchange) with the wall time of the transform,
@@ -35,6 +36,10 @@ def main():
     k0 = 987654321 % n
     for P in [int(v) for v in args.ranks.split(",")]:
         for ex in args.exchange.split(","):
+            if ex == "rccl" and P > ndev:
+                print(json.dumps({"config": f"C5 distributed fp64 c2c 2^{args.log2n} four-step", "ranks": P, "exchange": "rccl",
+                                  "skipped": f"RCCL refuses two ranks on one device ({ndev} device(s) visible)"}), flush=True)
+                continue
             with D.DistPlan(n, P, exchange=ex, chunks=args.chunks, natural_in=args.natural, natural_out=args.natural) as plan:
                 plan.fill("tone", k0)
                 best = None
