@@ -93,68 +93,80 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Waveforms whose sample needs fp64 libm beyond sine / cosine (exp, log, pow, tan, sinh, j0): their code costs ~100 more
+// registers than everything else together.  A kernel instantiated for one class only (CLS = GEN_LIGHT / GEN_HEAVY) returns 0
+// for the other class' names (the fused pipeline runs one kernel per class so that the common names fit 128 VGPRs).
+enum { GEN_ALL = 0, GEN_LIGHT = 1, GEN_HEAVY = 2 };
+__device__ __forceinline__ bool is_heavy_waveform(int wf) {
+    return wf == SA_WF_RUIDO_BRANCO || wf == SA_WF_EXP_DECAIMENTO || wf == SA_WF_TANGENTE || wf == SA_WF_GAUSSIANA ||
+           wf == SA_WF_HIPERBOLICA || wf == SA_WF_BESSEL || wf == SA_WF_PULSO_GAUSSIANO || wf == SA_WF_PULSO_EXPONENCIAL;
+}
+
 // One sample of _generate_waveform (main.py:536-615), before the vpp/2 scaling.
-template <typename TR = TrigF64>
+template <typename TR = TrigF64, int CLS = GEN_ALL>
 __device__ double gen_sample(const sa_gen_params& p, int64_t n, double tmean) {
+    if constexpr (CLS != GEN_ALL) {
+        if (is_heavy_waveform(p.waveform) != (CLS == GEN_HEAVY)) return 0.0;
+    }
     const double pi = 3.141592653589793, two_pi = 6.283185307179586;
     const double t = TR::time(n, p.Fs);                     // np.arange(N)/Fs  (main.py:460)
     const double tl = (double)(p.N - 1) / p.Fs;            // t[-1]
     const double Fc = p.Fc, Fm = p.Fm, dur = p.duration;
     const double x = two_pi * Fc * t;                      // ((2*pi)*Fc)*t, numpy's left-to-right order
     switch (p.waveform) {
-        case SA_WF_SENO: return TR::sin(x);
-        case SA_WF_COSSENO: return TR::cos(x);
-        case SA_WF_QUADRADA: return sp_square(x, 0.5);
-        case SA_WF_TRIANGULAR: return sp_sawtooth(x, 0.5);
-        case SA_WF_DENTE_DE_SERRA: return sp_sawtooth(x, 1.0);
-        case SA_WF_PULSO: return sp_square(x, 0.2);
-        case SA_WF_RUIDO_BRANCO: {
+        case SA_WF_SENO: if constexpr (CLS != GEN_HEAVY) return TR::sin(x);
+        case SA_WF_COSSENO: if constexpr (CLS != GEN_HEAVY) return TR::cos(x);
+        case SA_WF_QUADRADA: if constexpr (CLS != GEN_HEAVY) return sp_square(x, 0.5);
+        case SA_WF_TRIANGULAR: if constexpr (CLS != GEN_HEAVY) return sp_sawtooth(x, 0.5);
+        case SA_WF_DENTE_DE_SERRA: if constexpr (CLS != GEN_HEAVY) return sp_sawtooth(x, 1.0);
+        case SA_WF_PULSO: if constexpr (CLS != GEN_HEAVY) return sp_square(x, 0.2);
+        case SA_WF_RUIDO_BRANCO: if constexpr (CLS != GEN_LIGHT) {
             uint32_t r[4];
             philox4x32((uint32_t)(n >> 1), (uint32_t)((uint64_t)n >> 33), 0x6E6F6973u, 0u, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
             const double u1 = ((double)r[0] + 0.5) / 4294967296.0, u2 = ((double)r[1] + 0.5) / 4294967296.0;
             const double rad = sqrt(-2.0 * log(u1));
             return 0.5 * rad * ((n & 1) ? TR::sin(two_pi * u2) : TR::cos(two_pi * u2));
         }
-        case SA_WF_EXP_DECAIMENTO: return exp(-t / (dur / 5.0)) * TR::sin(x);
-        case SA_WF_PASSO: { const double tq = (double)(p.N / 4) / p.Fs; return (t - tq) >= 0.0 ? 1.0 : 0.0; }   // heaviside(.,1)
-        case SA_WF_RAMPA: return t / tl;
-        case SA_WF_PARABOLA: { const double r = t / tl; return r * r; }
-        case SA_WF_IMPULSO: return n == p.N / 2 ? 1.0 : 0.0;
-        case SA_WF_TANGENTE: { const double v = tan(pi * Fc * t); return fmin(fmax(v, -10.0), 10.0); }
-        case SA_WF_SINC: return np_sinc<TR>(2.0 * Fc * t);
-        case SA_WF_GAUSSIANA: { const double d = t - tmean, s = 0.1 * dur; return exp(-(d * d) / (s * s)) * TR::sin(x); }
-        case SA_WF_CHIRP_LINEAR: {         // scipy chirp 'linear': cos(2 pi (f0 t + 0.5 beta t^2)), f1 = 5 Fc, t1 = t[-1]
+        case SA_WF_EXP_DECAIMENTO: if constexpr (CLS != GEN_LIGHT) return exp(-t / (dur / 5.0)) * TR::sin(x);
+        case SA_WF_PASSO: if constexpr (CLS != GEN_HEAVY) { const double tq = (double)(p.N / 4) / p.Fs; return (t - tq) >= 0.0 ? 1.0 : 0.0; }   // heaviside(.,1)
+        case SA_WF_RAMPA: if constexpr (CLS != GEN_HEAVY) return t / tl;
+        case SA_WF_PARABOLA: if constexpr (CLS != GEN_HEAVY) { const double r = t / tl; return r * r; }
+        case SA_WF_IMPULSO: if constexpr (CLS != GEN_HEAVY) return n == p.N / 2 ? 1.0 : 0.0;
+        case SA_WF_TANGENTE: if constexpr (CLS != GEN_LIGHT) { const double v = tan(pi * Fc * t); return fmin(fmax(v, -10.0), 10.0); }
+        case SA_WF_SINC: if constexpr (CLS != GEN_HEAVY) return np_sinc<TR>(2.0 * Fc * t);
+        case SA_WF_GAUSSIANA: if constexpr (CLS != GEN_LIGHT) { const double d = t - tmean, s = 0.1 * dur; return exp(-(d * d) / (s * s)) * TR::sin(x); }
+        case SA_WF_CHIRP_LINEAR: if constexpr (CLS != GEN_HEAVY) {         // scipy chirp 'linear': cos(2 pi (f0 t + 0.5 beta t^2)), f1 = 5 Fc, t1 = t[-1]
             const double beta = (5.0 * Fc - Fc) / tl;
             return TR::cos(two_pi * (Fc * t + 0.5 * beta * t * t));
         }
-        case SA_WF_CHIRP_QUADRATICO: {     // 'quadratic', vertex_zero: cos(2 pi (f0 t + beta t^3/3)), f1 = 10 Fc
+        case SA_WF_CHIRP_QUADRATICO: if constexpr (CLS != GEN_HEAVY) {     // 'quadratic', vertex_zero: cos(2 pi (f0 t + beta t^3/3)), f1 = 10 Fc
             const double beta = (10.0 * Fc - Fc) / (tl * tl);
             return TR::cos(two_pi * (Fc * t + beta * (t * t * t) / 3.0));
         }
-        case SA_WF_ONDA_AM: return (1.0 + 0.5 * TR::sin(two_pi * Fm * t)) * TR::sin(x);
-        case SA_WF_ONDA_FM: return TR::sin(x + 5.0 * TR::sin(two_pi * Fm * t));
-        case SA_WF_BATIMENTO: return TR::sin(x) + TR::sin(two_pi * (Fc + Fm) * t);
-        case SA_WF_LORENTZIANA: return 1.0 / (1.0 + x * x);
-        case SA_WF_HIPERBOLICA: return sinh(x);
-        case SA_WF_BESSEL: return j0(x);
-        case SA_WF_SINC_MODULADO: return np_sinc<TR>(2.0 * Fc * t) * TR::sin(two_pi * Fm * t);
-        case SA_WF_PULSO_GAUSSIANO: {       // scipy gausspulse(t, fc, bw=0.5, bwr=-6): exp(-a t^2) cos(2 pi fc t)
+        case SA_WF_ONDA_AM: if constexpr (CLS != GEN_HEAVY) return (1.0 + 0.5 * TR::sin(two_pi * Fm * t)) * TR::sin(x);
+        case SA_WF_ONDA_FM: if constexpr (CLS != GEN_HEAVY) return TR::sin(x + 5.0 * TR::sin(two_pi * Fm * t));
+        case SA_WF_BATIMENTO: if constexpr (CLS != GEN_HEAVY) return TR::sin(x) + TR::sin(two_pi * (Fc + Fm) * t);
+        case SA_WF_LORENTZIANA: if constexpr (CLS != GEN_HEAVY) return 1.0 / (1.0 + x * x);
+        case SA_WF_HIPERBOLICA: if constexpr (CLS != GEN_LIGHT) return sinh(x);
+        case SA_WF_BESSEL: if constexpr (CLS != GEN_LIGHT) return j0(x);
+        case SA_WF_SINC_MODULADO: if constexpr (CLS != GEN_HEAVY) return np_sinc<TR>(2.0 * Fc * t) * TR::sin(two_pi * Fm * t);
+        case SA_WF_PULSO_GAUSSIANO: if constexpr (CLS != GEN_LIGHT) {       // scipy gausspulse(t, fc, bw=0.5, bwr=-6): exp(-a t^2) cos(2 pi fc t)
             const double ref = pow(10.0, -6.0 / 20.0);
             const double pb = pi * Fc * 0.5;
             const double a = -(pb * pb) / (4.0 * log(ref));
             return exp(-a * t * t) * TR::cos(two_pi * Fc * t);
         }
-        case SA_WF_DENTE_DE_SERRA_MOD: return sp_sawtooth(x, 0.3);
-        case SA_WF_ONDA_AM_DSB: return TR::sin(x) * TR::sin(two_pi * Fm * t);
-        case SA_WF_ONDA_FM_ESTEREO: {
+        case SA_WF_DENTE_DE_SERRA_MOD: if constexpr (CLS != GEN_HEAVY) return sp_sawtooth(x, 0.3);
+        case SA_WF_ONDA_AM_DSB: if constexpr (CLS != GEN_HEAVY) return TR::sin(x) * TR::sin(two_pi * Fm * t);
+        case SA_WF_ONDA_FM_ESTEREO: if constexpr (CLS != GEN_HEAVY) {
             const double m = 3.0 * TR::sin(two_pi * Fm * t);
             return 0.5 * (TR::sin(x + m) + TR::sin(two_pi * (Fc + 1000.0) * t + m));
         }
-        case SA_WF_QUADRADA_MODULADA: return sp_square(x, 0.5) * (1.0 + 0.5 * TR::sin(two_pi * Fm * t));
-        case SA_WF_TRIANGULAR_MODULADA: return sp_sawtooth(x, 0.5) * (1.0 + 0.3 * TR::sin(two_pi * Fm * t));
-        case SA_WF_PULSO_EXPONENCIAL: return exp(-5.0 * t / dur) * TR::sin(x);
-        case SA_WF_ONDA_COMB: { const double v = TR::sin(x) + 0.7; return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0); }
-        case SA_WF_ONDA_HARMONICA: return TR::sin(x) + 0.5 * TR::sin(two_pi * 2.0 * Fc * t);
+        case SA_WF_QUADRADA_MODULADA: if constexpr (CLS != GEN_HEAVY) return sp_square(x, 0.5) * (1.0 + 0.5 * TR::sin(two_pi * Fm * t));
+        case SA_WF_TRIANGULAR_MODULADA: if constexpr (CLS != GEN_HEAVY) return sp_sawtooth(x, 0.5) * (1.0 + 0.3 * TR::sin(two_pi * Fm * t));
+        case SA_WF_PULSO_EXPONENCIAL: if constexpr (CLS != GEN_LIGHT) return exp(-5.0 * t / dur) * TR::sin(x);
+        case SA_WF_ONDA_COMB: if constexpr (CLS != GEN_HEAVY) { const double v = TR::sin(x) + 0.7; return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0); }
+        case SA_WF_ONDA_HARMONICA: if constexpr (CLS != GEN_HEAVY) return TR::sin(x) + 0.5 * TR::sin(two_pi * 2.0 * Fc * t);
         default: return 0.0;                // unknown name -> np.zeros_like(t)  (main.py:614-615)
     }
 }
@@ -173,7 +185,7 @@ __device__ __forceinline__ double sin_prefix_sum(double a, int64_t n) {
 }
 
 // y[n] of main.py:460-472 with the FM integral in closed form.
-template <typename TR = TrigF64>
+template <typename TR = TrigF64, int CLS = GEN_ALL>
 __device__ __forceinline__ double modulated_sample(const sa_gen_params& p, int64_t n) {
     const double two_pi = 6.283185307179586;
     const double t = TR::time(n, p.Fs);
@@ -187,7 +199,7 @@ __device__ __forceinline__ double modulated_sample(const sa_gen_params& p, int64
         const double acc = sin_prefix_sum<TP>(two_pi * p.Fm / p.Fs, n);
         return TR::sin(two_pi * p.Fc * t + two_pi * p.fm_dev * acc * (1.0 / p.Fs));
     }
-    double v = gen_sample<TR>(p, n, 0.5 * (double)(p.N - 1) / p.Fs);
+    double v = gen_sample<TR, CLS>(p, n, 0.5 * (double)(p.N - 1) / p.Fs);
     if (p.apply_vpp) v = v * p.vpp_half;
     if (!premod && p.am_on) v = v * (1.0 + p.am_depth * TR::sin(two_pi * p.Fm * t));
     return v;

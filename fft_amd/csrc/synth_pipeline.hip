@@ -44,8 +44,12 @@ struct PipeArgs {
     float* y_out;                 // [batch][n] upsampled time signal, or nullptr
 };
 
-template <int LOG2M, int U, int PP>
-__global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kernel(PipeArgs a) {
+// CLS: the generator class this instantiation serves (synth_gen.h).  The launch runs one kernel per class, each skipping
+// the other's frames: the GEN_LIGHT kernel (every name but the eight that need fp64 exp / log / pow / tan / sinh / j0) fits
+// 128 VGPRs, so two of its 512-thread workgroups share a CU; the GEN_HEAVY kernel keeps the 256-register budget.
+template <int LOG2M, int U, int PP, int CLS>
+__global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF), (CLS == GEN_LIGHT && FftPlan<LOG2M, PP>::TPF >= 512 ? 4 : 1))
+synth_pipeline_kernel(PipeArgs a) {
     using PL = FftPlan<LOG2M, PP>;
     constexpr int M = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
     constexpr int N = 2 * M;
@@ -53,47 +57,60 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
     constexpr int S = LdsPadShift<float>::value;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* buf = reinterpret_cast<float2*>(smem_raw);
-    float* yb = reinterpret_cast<float*>(buf + lds_fft_elems<float, LOG2M>());   // [NB] base samples
+    // The base samples, knot derivatives and per-interval coefficients are dead once the upsampled frame sits in the
+    // registers of FFT pass 0, so they live INSIDE the transform buffer (24 NB = 6 M bytes of its 8 M): the workgroup
+    // needs 70 KiB instead of 116 and two of them share a CU — one's barriers hide behind the other's arithmetic.
+    float* yb = reinterpret_cast<float*>(smem_raw);                               // [NB] base samples
     float* sb = yb + NB;                                                          // [NB] knot derivatives
-    constexpr int NW = (TPF + 63) / 64;
-    float* red_m = (U > 1) ? sb + NB : sb;              // no derivative array without upsampling
-    int* red_k = reinterpret_cast<int*>(red_m + NW);
     // per-interval cubic coefficients (y0, s0, slope - s0 - tt, tt): one 16-byte read per evaluated sample
-    float4* cf = reinterpret_cast<float4*>(smem_raw + (((size_t)(reinterpret_cast<char*>(red_k + NW) - smem_raw) + 15) & ~(size_t)15));
+    float4* cf = reinterpret_cast<float4*>(smem_raw + (size_t)NB * 8);
+    static_assert((U > 1 ? 24 : 4) * NB <= 8 * M, "the staging arrays fit inside the transform buffer");
+    constexpr int NW = (TPF + 63) / 64;
+    float* red_m = reinterpret_cast<float*>(buf + lds_fft_elems<float, LOG2M>());
+    int* red_k = reinterpret_cast<int*>(red_m + NW);
     const int tl = threadIdx.x;
     const bool excl = a.flags & SA_F_EXCLUDE_DC_NYQ;
     const bool wmag = (a.flags & SA_F_WRITE_MAG) && a.mag;
     const bool wdb = a.flags & SA_F_DB;
-    // Launch constants of the thread (it handles the same positions of every frame): window samples,
-    // FFT twiddles and the Hermitian factors w_n^q stay in registers.
-    float2 w[P];
-    if (a.win) {
+    // Launch constants of the thread (it handles the same positions of every frame): the FFT twiddles always stay in
+    // registers; window samples and the Hermitian factors w_n^q too in the small workgroups.  The 512-thread workgroups
+    // (n >= 8192) reload those 48 registers from L2 per frame instead: with the fp64 generator's footprint that is what
+    // lets the kernel fit 128 VGPRs, i.e. two workgroups per CU.
+    constexpr bool HOIST = TPF < 512;
+    constexpr int NIT = (M / 2) / TPF;
+    float2 w[HOIST ? P : 1];
+    float2 tn[HOIST ? NIT : 1];
+    auto load_window = [&](float2* wd, int lane) {
+        if (a.win) {
 #pragma unroll
-        for (int u = 0; u < P / R0; ++u)
+            for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1)
-                w[u * R0 + n1] = reinterpret_cast<const float2*>(a.win)[n1 * (M / R0) + tl + TPF * u];
-    } else {
+                for (int n1 = 0; n1 < R0; ++n1)
+                    wd[u * R0 + n1] = reinterpret_cast<const float2*>(a.win)[n1 * (M / R0) + lane + TPF * u];
+        } else {
 #pragma unroll
-        for (int i = 0; i < P; ++i) w[i] = mk<float>(1.f, 1.f);
+            for (int i = 0; i < P; ++i) wd[i] = mk<float>(1.f, 1.f);
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) { wd[i].x *= 0.5f; wd[i].y *= 0.5f; }     // the 1/2 of the Hermitian split (exact)
+    };
+    if constexpr (HOIST) {
+        load_window(w, tl);
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tl + TPF * u];
     }
-#pragma unroll
-    for (int i = 0; i < P; ++i) { w[i].x *= 0.5f; w[i].y *= 0.5f; }     // the 1/2 of the Hermitian split (exact)
     TwRegs<float, LOG2M, PP> tw;
     tw.load(a.twM, tl);
-    constexpr int NIT = (M / 2) / TPF;
-    float2 tn[NIT];
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tl + TPF * u];
 
     for (int64_t f = blockIdx.x; f < a.batch; f += gridDim.x) {
         sa_gen_params p = a.params[f];
+        if (is_heavy_waveform(p.waveform) != (CLS == GEN_HEAVY)) continue;      // uniform: the whole workgroup skips the frame
         p.N = NB;
         int tq = tl;                                    // opaque per frame (keeps address math out of the loop-invariant set)
         asm volatile("" : "+v"(tq));
         tq &= TPF - 1;
         // ---- 1. synthesis at the base rate (fp64 phase, fp32 sample) ---------------------------------
-        for (int i = tq; i < NB; i += TPF) yb[i] = (float)modulated_sample<TrigF32>(p, i);
+        for (int i = tq; i < NB; i += TPF) yb[i] = (float)modulated_sample<TrigF32, CLS>(p, i);
         __syncthreads();
         // ---- 2. knot derivatives (per knot spacing) ---------------------------------------------------
         if constexpr (U > 1) {
@@ -154,8 +171,16 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
 #pragma unroll
                 for (int n1 = 0; n1 < R0; ++n1) yo[n1 * (M / R0) + tq + TPF * u] = v[u * R0 + n1];
         }
+        if constexpr (HOIST) {
 #pragma unroll
-        for (int i = 0; i < P; ++i) { v[i].x *= w[i].x; v[i].y *= w[i].y; }
+            for (int i = 0; i < P; ++i) { v[i].x *= w[i].x; v[i].y *= w[i].y; }
+        } else {
+            float2 wl[P];
+            load_window(wl, tq);
+#pragma unroll
+            for (int i = 0; i < P; ++i) { v[i].x *= wl[i].x; v[i].y *= wl[i].y; }
+        }
+        __syncthreads();                                // every thread has its samples: the staging arrays may be overwritten
         lds_fft_tw<float, LOG2M, PP>(v, buf, tl, tw);
         // ---- 4. Hermitian post-pass, magnitudes, peak ---------------------------------------------------
         asm volatile("" : "+v"(tq));
@@ -176,6 +201,11 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
             // every lane but tq = 0 (see rfft_generic.h)
             const float2* pq = buf + lds_pad<S>(tq);
             const int mlow = lds_pad<S>(TPF - tq);
+            float2 tl_[HOIST ? 1 : NIT];
+            if constexpr (!HOIST) {
+#pragma unroll
+                for (int u = 0; u < NIT; ++u) tl_[u] = a.twN[tq + TPF * u];
+            }
 #pragma unroll
             for (int u = 0; u < NIT; ++u) {                 // pair q < M/2 -> bins q and M - q
                 const int q = tq + TPF * u;
@@ -184,7 +214,7 @@ __global__ void __launch_bounds__((FftPlan<LOG2M, PP>::TPF)) synth_pipeline_kern
                 const float2 zq = pq[lds_pad_c<S>(TPF * u)], zm = buf[(tq == 0 ? m0 : mlow) + moff];
                 const float2 e = mk<float>(zq.x + zm.x, zq.y - zm.y);          // the 1/2 is in the window
                 const float2 d = mk<float>(zq.x - zm.x, zq.y + zm.y);
-                const float2 wo = cmul(mk<float>(d.y, -d.x), tn[u]);
+                const float2 wo = cmul(mk<float>(d.y, -d.x), HOIST ? tn[u] : tl_[u]);
                 const float2 xa = cadd(e, wo), xb = csub(e, wo);
                 consider(mag_sqrt(xa.x * xa.x + xa.y * xa.y), q, tq * 4, TPF * u * 4);
                 consider(mag_sqrt(xb.x * xb.x + xb.y * xb.y), M - q, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
@@ -262,12 +292,18 @@ template <int LOG2M, int U, int PP>
 static int launch_pipe_pp(const PipeArgs& a, hipStream_t st) {
     constexpr int NBASE = (2 << LOG2M) / U;
     constexpr int NW = (FftPlan<LOG2M, PP>::TPF + 63) / 64;
-    constexpr int lds = lds_fft_elems<float, LOG2M>() * 8 + (U > 1 ? 2 : 1) * NBASE * 4 + NW * 8 + 32 + (U > 1 ? NBASE * 16 : 0);
-    auto kern = synth_pipeline_kernel<LOG2M, U, PP>;
-    static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
+    constexpr int lds = lds_fft_elems<float, LOG2M>() * 8 + NW * 8 + 32;                  // staging arrays alias the transform buffer
+    (void)NBASE;
+    auto kern = synth_pipeline_kernel<LOG2M, U, PP, GEN_LIGHT>;
+    auto kern_heavy = synth_pipeline_kernel<LOG2M, U, PP, GEN_HEAVY>;
+    static thread_local uint64_t attr_devs = 0, attr_devs_heavy = 0;   // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern_heavy), (int)lds, &attr_devs_heavy));
     const int64_t cap = grid_cap(4, "PIPE");
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(FftPlan<LOG2M, PP>::TPF), lds, st, a);
+    SA_HIP(hipGetLastError());
+    // the frames of the eight libm-heavy names (a workgroup of the other class reads a frame's 64-byte record and moves on)
+    hipLaunchKernelGGL(kern_heavy, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(FftPlan<LOG2M, PP>::TPF), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
