@@ -519,7 +519,6 @@ int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double 
     cplx<T>* work[4] = {};
     RlCand* cand[4] = {};
     hipStream_t ls[4] = {st, nullptr, nullptr, nullptr};
-    hipEvent_t ev_in = nullptr, ev_done[4] = {};
     int rc = SA_OK;
     for (int l = 0; l < lanes && rc == SA_OK; ++l) {
         work[l] = static_cast<cplx<T>*>(tmp.dev((size_t)chunk * wframe));
@@ -527,13 +526,15 @@ int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double 
         if (!work[l] || !cand[l]) rc = SA_ENOMEM;
         if (l > 0 && rc == SA_OK) {
             ls[l] = thread_aux_stream(l - 1);
-            if (!ls[l] || hipEventCreateWithFlags(&ev_done[l], hipEventDisableTiming) != hipSuccess) { set_error("rfft multi-pass path: no auxiliary stream / event"); rc = SA_EHIP; }
+            if (!ls[l]) { set_error("rfft multi-pass path: no auxiliary stream"); rc = SA_EHIP; }
         }
     }
-    if (rc == SA_OK && lanes > 1) {                        // the lanes start after whatever the caller queued on `st` before this call
-        if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev_in, st) != hipSuccess) { set_error("rfft multi-pass path: event"); rc = SA_EHIP; }
-        for (int l = 1; l < lanes && rc == SA_OK; ++l)
-            if (hipStreamWaitEvent(ls[l], ev_in, 0) != hipSuccess) { set_error("rfft multi-pass path: stream wait"); rc = SA_EHIP; }
+    // The extra lanes start after whatever the caller queued on `st` before this call.  The call synchronises at its end
+    // anyway, so the order is made on the host (no event is recorded on, or waited for by, the caller's stream: `st` may be
+    // one of the special handles — hipStreamLegacy, hipStreamPerThread — that not every event call accepts).
+    if (rc == SA_OK && lanes > 1) {
+        const hipError_t e0 = hipStreamSynchronize(st);
+        if (e0 != hipSuccess) { set_error("rfft multi-pass path: %s", hipGetErrorString(e0)); rc = SA_EHIP; }
     }
     int64_t ci = 0;
     for (int64_t b0 = 0; rc == SA_OK && b0 < batch; b0 += chunk, ++ci) {
@@ -555,18 +556,14 @@ int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double 
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("rfft multi-pass kernels: %s", hipGetErrorString(e)); rc = SA_EHIP; }
     }
-    // the arena goes back with nothing in flight: every lane is drained, and `st` is ordered after all of them
+    // the arena goes back with nothing in flight: every lane is drained before the call returns
     for (int l = 1; l < lanes; ++l) {
         if (!ls[l]) continue;
-        if (ev_done[l] && hipEventRecord(ev_done[l], ls[l]) == hipSuccess) (void)hipStreamWaitEvent(st, ev_done[l], 0);
         const hipError_t e = hipStreamSynchronize(ls[l]);
         if (rc == SA_OK && e != hipSuccess) { set_error("rfft multi-pass path: %s", hipGetErrorString(e)); rc = SA_EHIP; }
     }
     const hipError_t e = hipStreamSynchronize(st);
     if (rc == SA_OK && e != hipSuccess) { set_error("rfft multi-pass path: %s", hipGetErrorString(e)); rc = SA_EHIP; }
-    if (ev_in) (void)hipEventDestroy(ev_in);
-    for (int l = 1; l < 4; ++l)
-        if (ev_done[l]) (void)hipEventDestroy(ev_done[l]);
     return rc;
 }
 template int rfft_large_dev<float>(const float*, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);

@@ -99,6 +99,35 @@ def test_rfft_long_frames_multi_pass(dtype, log2n, batch, win):
         np.testing.assert_array_equal(pb3, pb); np.testing.assert_array_equal(pm3, pm)
 
 
+def test_rfft_long_frames_dev_entry_on_every_kind_of_stream():
+    """The device entry point of the multi-pass path keeps two chunks in flight on streams of its own and orders them
+    against the caller's stream on the host: the caller may pass NULL (library stream), hipStreamLegacy (what torch's
+    default stream maps to — event calls on that handle crashed an earlier version) or an ordinary stream."""
+    import ctypes as C
+    import torch
+    from fft_amd import _lib
+    lib = _lib.load()
+    n, batch = 1 << 16, 700                       # several 64 MiB chunks
+    x = torch.randn(batch, n, device="cuda")
+    outs = []
+    side = torch.cuda.Stream()
+    for which in ("null", "legacy", "side"):
+        mag = torch.zeros(batch, n // 2 + 1, device="cuda")
+        pb = torch.zeros(batch, dtype=torch.int32, device="cuda")
+        pm = torch.zeros(batch, device="cuda")
+        torch.cuda.synchronize()
+        st = None if which == "null" else C.c_void_p(1) if which == "legacy" else C.c_void_p(side.cuda_stream)
+        _lib.check(lib.sa_rfft_peak_f32_dev(C.c_void_p(x.data_ptr()), batch, n, _lib.WIN_HANN, 0.0, _lib.F_WRITE_MAG, C.c_void_p(mag.data_ptr()),
+                                            C.c_void_p(pb.data_ptr()), C.c_void_p(pm.data_ptr()), st))
+        outs.append((mag.cpu().numpy(), pb.cpu().numpy(), pm.cpu().numpy()))      # the call has synchronised
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            np.testing.assert_array_equal(a, b)
+    mref, pbref, _ = O.rfft_mag_peak(x[:3].cpu().numpy(), "hann")
+    assert rel_l2(outs[0][0][:3], mref).max() < 1e-6
+    check_peaks(outs[0][1][:3], outs[0][2][:3], mref, pbref)
+
+
 def test_rfft_long_frame_dc_and_nyquist_and_anylen_route():
     """DC-only and alternating +-1 frames put the peak on the two self-paired bins; sa_fft_mag_f64 routes a 2^16-point
     frame through the same path."""
