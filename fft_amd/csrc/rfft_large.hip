@@ -307,15 +307,15 @@ __global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * B)) rl_final_pass(RlAr
     }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(1024) rl_peak_kernel(const RlCand* __restrict__ cand, int64_t ncand, int32_t* __restrict__ peak_bin,
-                                                       T* __restrict__ peak_mag) {
+template <typename T, int NT>
+__global__ void __launch_bounds__(NT) rl_peak_kernel(const RlCand* __restrict__ cand, int64_t ncand, int32_t* __restrict__ peak_bin,
+                                                     T* __restrict__ peak_mag) {
     __shared__ double sm[16];
     __shared__ long long sk[16];
     const int64_t b = blockIdx.x;
     double best = -1.0;
     int64_t bk = INT64_MAX;
-    for (int64_t i = threadIdx.x; i < ncand; i += 1024) {
+    for (int64_t i = threadIdx.x; i < ncand; i += NT) {
         const RlCand c = cand[b * ncand + i];
         if (rl_better(c.m, c.k, best, bk)) { best = c.m; bk = c.k; }
     }
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(1024) rl_peak_kernel(const RlCand* __restrict_
     if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = best; sk[threadIdx.x >> 6] = bk; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w)
+        for (int w = 1; w < NT / 64; ++w)
             if (rl_better(sm[w], sk[w], best, bk)) { best = sm[w]; bk = sk[w]; }
         peak_bin[b] = (int32_t)bk;
         peak_mag[b] = (T)best;
@@ -552,7 +552,8 @@ int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double 
         }
         if ((rc = rl_set_twiddles(a, lf, 0)) != SA_OK) break;
         if ((rc = rl_dispatch<T>(2, lf, a, s)) != SA_OK) break;
-        hipLaunchKernelGGL(rl_peak_kernel<T>, dim3((unsigned)a.batch), dim3(1024), 0, s, a.cand, ncand, peak_bin + b0, peak_mag + b0);
+        if (ncand <= 2048) hipLaunchKernelGGL((rl_peak_kernel<T, 128>), dim3((unsigned)a.batch), dim3(128), 0, s, a.cand, ncand, peak_bin + b0, peak_mag + b0);
+        else hipLaunchKernelGGL((rl_peak_kernel<T, 1024>), dim3((unsigned)a.batch), dim3(1024), 0, s, a.cand, ncand, peak_bin + b0, peak_mag + b0);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("rfft multi-pass kernels: %s", hipGetErrorString(e)); rc = SA_EHIP; }
     }
