@@ -10,6 +10,7 @@
 //        M = next power of two >= 2n-1; k^2 mod 2n is taken in integers so the chirp is exact to fp64.
 // Outputs bins 0..n/2 (the shim mirrors them into the reference's fftshift layout) and the peak.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <stdio.h>
@@ -19,7 +20,7 @@
 #include <string>
 #include <vector>
 
-#include "fft_core.h"
+#include "lds_fft.h"
 #include "runtime.h"
 
 namespace sa {
@@ -93,6 +94,102 @@ __global__ void __launch_bounds__(256) blu_peak(const Cd* __restrict__ a, int64_
         __syncthreads();
     }
     if (threadIdx.x == 0) { peak_bin[b] = (int32_t)sk[0]; peak_mag[b] = sm[0]; }
+}
+
+// ---- one-kernel form for the GUI's frames (n <= 4096, i.e. M <= 8192: the whole chirp-z fits one workgroup's LDS) --------
+// prep -> FFT_M -> x filter spectrum -> inverse FFT_M -> |.| (dB) -> peak, one workgroup per frame, the same algorithm and
+// tables as the kernel chain above (the two agree to a few ulp: the compiler contracts multiply-adds differently); what it
+// saves is five kernel launches per call, which is most of the latency of a single 1500- or 2000-point frame.
+struct BluFusedArgs {
+    const double* x; const double* win; const Cd* chirp; const Cd* fb; const Cd* twR;
+    double* mag; int32_t* peak_bin; double* peak_mag;
+    int64_t n, nb;
+    int flags;
+    double scale, db_floor;
+};
+template <int LR>
+__global__ void __launch_bounds__((FftPlan<LR, 8>::TPF)) blu_fused_kernel(BluFusedArgs a) {
+    using PL = FftPlan<LR, 8>;
+    constexpr int M = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
+    constexpr int S = LdsPadShift<double>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Cd* buf = reinterpret_cast<Cd*>(smem_raw);
+    constexpr int NW = (TPF + 63) / 64;
+    double* red_m = reinterpret_cast<double*>(buf + lds_fft_elems<double, LR>());
+    long long* red_k = reinterpret_cast<long long*>(red_m + NW);
+    const int tl = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const double* xf = a.x + b * a.n;
+    Cd v[P];
+#pragma unroll
+    for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+        for (int n1 = 0; n1 < R0; ++n1) {
+            const int k = n1 * (M / R0) + tl + TPF * u;
+            Cd z = mk<double>(0.0, 0.0);
+            if (k < a.n) {
+                double t = xf[k];
+                if (a.win) t *= a.win[k];
+                z.x = t * a.chirp[k].x; z.y = t * a.chirp[k].y;
+            }
+            v[u * R0 + n1] = z;
+        }
+    lds_fft<double, LR, 8>(v, buf, tl, a.twR);
+#pragma unroll
+    for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+        for (int n1 = 0; n1 < R0; ++n1) {
+            const int k = n1 * (M / R0) + tl + TPF * u;
+            const Cd p = cmul(buf[lds_pad<S>(k)], a.fb[k]);
+            v[u * R0 + n1] = mk<double>(p.x, -p.y);                  // inverse transform: conjugate in, conjugate + 1/M out
+        }
+    __syncthreads();                                                 // everyone has read the first spectrum
+    lds_fft<double, LR, 8>(v, buf, tl, a.twR);
+    const bool excl = a.flags & SA_F_EXCLUDE_DC_NYQ, db = a.flags & SA_F_DB;
+    double* mf = (a.flags & SA_F_WRITE_MAG) && a.mag ? a.mag + b * a.nb : nullptr;
+    double best = -1.0;
+    long long bk = 0x7fffffffffffffffLL;
+    for (int64_t k = tl; k < a.nb; k += TPF) {
+        Cd z = buf[lds_pad<S>((int)k)];
+        z.x *= a.scale; z.y *= a.scale;
+        z.y = -z.y;
+        const double m = hypot(z.x, z.y);
+        if (mf) mf[k] = db ? 20.0 * log10(fmax(m, a.db_floor)) : m;
+        if (excl && (k == 0 || (a.n % 2 == 0 && k == a.nb - 1))) continue;
+        if (m > best) { best = m; bk = k; }                          // ascending k per thread: first max kept
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double om = __shfl_xor(best, off);
+        const long long ok = __shfl_xor(bk, off);
+        if (om > best || (om == best && ok < bk)) { best = om; bk = ok; }
+    }
+    if ((tl & 63) == 0) { red_m[tl >> 6] = best; red_k[tl >> 6] = bk; }
+    __syncthreads();
+    if (tl == 0) {
+        for (int w = 1; w < NW; ++w)
+            if (red_m[w] > best || (red_m[w] == best && red_k[w] < bk)) { best = red_m[w]; bk = red_k[w]; }
+        a.peak_bin[b] = (int32_t)bk;
+        a.peak_mag[b] = best;
+    }
+}
+template <int LR> static int launch_blu_fused(const BluFusedArgs& a, int64_t cnt, hipStream_t st) {
+    constexpr int NW = (FftPlan<LR, 8>::TPF + 63) / 64;
+    constexpr int lds = lds_fft_elems<double, LR>() * 16 + NW * 16;
+    static_assert(lds <= 160 * 1024, "fused chirp-z does not fit LDS");
+    auto kern = blu_fused_kernel<LR>;
+    static thread_local uint64_t attr_devs = 0;
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs));
+    hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(FftPlan<LR, 8>::TPF), lds, st, a);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+struct BluTwCtx { int64_t n; };
+static void fill_blu_tw(void* host, void* ctx) {
+    const int64_t n = static_cast<BluTwCtx*>(ctx)->n;
+    std::vector<double> t;
+    host_twiddle(n, n, 1, t);
+    memcpy(host, t.data(), t.size() * sizeof(double));
 }
 
 // ---- host tables --------------------------------------------------------------------------------------
@@ -202,6 +299,31 @@ int fft_mag_any_dev(const double* dx, int64_t cnt, int64_t n, int window, double
     BluPlan bp{nullptr, nullptr, n};
     if (!pow2) SA_TRY(get_blu_plan(n, st, &bp));
     const int64_t M = pow2 ? n : bp.M;
+    // few short frames (the GUI's calls): the whole chirp-z in one kernel per frame.  SA_BLU_FUSED=0 keeps the kernel chain.
+    static const bool fused_on = !(getenv("SA_BLU_FUSED") && atoi(getenv("SA_BLU_FUSED")) == 0);
+    if (!pow2 && fused_on && M >= 64 && M <= 8192 && cnt <= 256) {
+        BluTwCtx tc{M};
+        BluFusedArgs fa{};
+        fa.twR = static_cast<const Cd*>(get_cached_table("tw64:" + std::to_string(M) + ":" + std::to_string(M) + ":1", (size_t)M * 16, fill_blu_tw, &tc));
+        if (!fa.twR) return SA_EHIP;
+        fa.x = dx; fa.win = dwin; fa.chirp = bp.chirp; fa.fb = bp.fb; fa.mag = dmag; fa.peak_bin = dpb; fa.peak_mag = dpm;
+        fa.n = n; fa.nb = nb; fa.flags = flags; fa.scale = 1.0 / (double)M; fa.db_floor = SA_DB_FLOOR_F64;
+        int l = 0;
+        while ((1LL << l) < M) ++l;
+        int rc = SA_EUNSUP;
+        switch (l) {
+            case 6: rc = launch_blu_fused<6>(fa, cnt, st); break;
+            case 7: rc = launch_blu_fused<7>(fa, cnt, st); break;
+            case 8: rc = launch_blu_fused<8>(fa, cnt, st); break;
+            case 9: rc = launch_blu_fused<9>(fa, cnt, st); break;
+            case 10: rc = launch_blu_fused<10>(fa, cnt, st); break;
+            case 11: rc = launch_blu_fused<11>(fa, cnt, st); break;
+            case 12: rc = launch_blu_fused<12>(fa, cnt, st); break;
+            case 13: rc = launch_blu_fused<13>(fa, cnt, st); break;
+        }
+        if (rc == SA_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("fft_mag fused kernel failed"); rc = SA_EHIP; }
+        return rc;
+    }
     Temp tmp;
     Cd* da = static_cast<Cd*>(tmp.dev((size_t)cnt * M * 16));
     Cd* dbuf = static_cast<Cd*>(tmp.dev((size_t)cnt * M * 16));
@@ -254,26 +376,31 @@ extern "C" int sa_fft_mag_f64(const double* x, int64_t batch, int64_t n, int32_t
     const bool wm = (flags & SA_F_WRITE_MAG) != 0;
     const size_t ox = 0, om = ox + (size_t)chunk * n * 8, opm = om + (wm ? (size_t)chunk * nb * 8 : 0);
     const size_t opb = opm + (size_t)chunk * 8, total = opb + (((size_t)chunk * 4 + 7) & ~(size_t)7);
+    // Small calls (the GUI's single frames): the kernels read the frame from, and write the results to, the pinned block
+    // itself (it is mapped into the device's address space) — two copy submissions and their completion latency less per
+    // call (N = 4096: 50 -> ~30 us through the Python shim).  SA_ZEROCOPY_MAX (bytes, 0 = off) moves the threshold.
+    const bool zc = total <= zero_copy_max();
     Temp tmp;
-    char* d = static_cast<char*>(tmp.dev(total));
     char* h = static_cast<char*>(tmp.pinned(total));
+    char* d = zc ? h : static_cast<char*>(tmp.dev(total));
     if (!d || !h) return SA_ENOMEM;
     int rc = SA_OK;
     for (int64_t b0 = 0; rc == SA_OK && b0 < batch; b0 += chunk) {
         const int64_t cnt = batch - b0 < chunk ? batch - b0 : chunk;
         memcpy(h + ox, x + b0 * n, (size_t)cnt * n * 8);
-        hipError_t e = hipMemcpyAsync(d + ox, h + ox, (size_t)cnt * n * 8, hipMemcpyHostToDevice, st);
+        hipError_t e = zc ? hipSuccess : hipMemcpyAsync(d + ox, h + ox, (size_t)cnt * n * 8, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { set_error("H2D failed: %s", hipGetErrorString(e)); rc = SA_EHIP; break; }
         rc = fft_mag_any_dev(reinterpret_cast<double*>(d + ox), cnt, n, window, win_param, flags,
                              wm ? reinterpret_cast<double*>(d + om) : nullptr, reinterpret_cast<int32_t*>(d + opb),
                              reinterpret_cast<double*>(d + opm), st);
         if (rc != SA_OK) break;
-        e = hipMemcpyAsync(h + om, d + om, total - om, hipMemcpyDeviceToHost, st);
+        if (!zc) e = hipMemcpyAsync(h + om, d + om, total - om, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("D2H failed: %s", hipGetErrorString(e)); rc = SA_EHIP; break; }
         if (wm) memcpy(mag + b0 * nb, h + om, (size_t)cnt * nb * 8);
         memcpy(peak_mag + b0, h + opm, (size_t)cnt * 8);
         memcpy(peak_bin + b0, h + opb, (size_t)cnt * 4);
     }
+    if (rc != SA_OK) (void)hipStreamSynchronize(st);      // nothing may still be using the blocks when they are handed back
     return rc;
 }

@@ -108,6 +108,9 @@ class Temp {
     std::vector<void*> dextra_, hextra_;
 };
 int thread_state_count();
+// host-pointer calls whose whole staging block is at most this many bytes skip the device copy: the kernels work on the
+// pinned block directly (SA_ZEROCOPY_MAX, default 512 KiB; 0 = never)
+size_t zero_copy_max();
 // workgroups a grid-stride kernel is capped at: per_cu x CUs x an optional tuning factor from the environment
 // (SA_GRIDX_<family> = percent, e.g. 400 = four times as many workgroups)
 int64_t grid_cap(int per_cu, const char* family);

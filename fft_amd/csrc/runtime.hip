@@ -54,6 +54,11 @@ void open_gate() { g_closing.store(false, std::memory_order_release); }
 int num_cus() { return g_ncus; }
 bool initialised() { return g_inited.load(std::memory_order_acquire); }
 
+size_t zero_copy_max() {
+    static const size_t v = getenv("SA_ZEROCOPY_MAX") ? (size_t)atoll(getenv("SA_ZEROCOPY_MAX")) : (size_t)512 << 10;
+    return v;
+}
+
 int64_t grid_cap(int per_cu, const char* family) {
     char name[64];
     snprintf(name, sizeof(name), "SA_GRIDX_%s", family);

@@ -116,9 +116,11 @@ int sa_compute_f64(const sa_gen_params* p, int32_t window, double win_param, int
     // one device block [y | t | mag | peak_mag | peak_bin] and one pinned mirror: a single D2H per call
     const size_t oy = 0, ot = oy + (size_t)n * 8, om = ot + (t_out ? (size_t)n * 8 : 0), opm = om + (size_t)nb * 8, opb = opm + 8;
     const size_t total = opb + 8;
+    // small frames (the GUI's): the kernels write straight into the pinned block, no device copy (runtime.h: zero_copy_max)
+    const bool zc = total <= zero_copy_max();
     Temp tmp;
-    char* d = static_cast<char*>(tmp.dev(total));
     char* h = static_cast<char*>(tmp.pinned(total));
+    char* d = zc ? h : static_cast<char*>(tmp.dev(total));
     if (!d || !h) return SA_ENOMEM;
     double* dy = reinterpret_cast<double*>(d + oy);
     double* dt = t_out ? reinterpret_cast<double*>(d + ot) : nullptr;
@@ -126,8 +128,9 @@ int sa_compute_f64(const sa_gen_params* p, int32_t window, double win_param, int
     if (rc == SA_OK)
         rc = fft_mag_any_dev(dy, 1, n, window, win_param, flags, reinterpret_cast<double*>(d + om),
                              reinterpret_cast<int32_t*>(d + opb), reinterpret_cast<double*>(d + opm), st);
+    if (rc != SA_OK) (void)hipStreamSynchronize(st);
     if (rc == SA_OK) {
-        hipError_t e = hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, st);
+        hipError_t e = zc ? hipSuccess : hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("sa_compute_f64: %s", hipGetErrorString(e)); return SA_EHIP; }
         memcpy(y_out, h + oy, (size_t)n * 8);

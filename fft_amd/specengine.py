@@ -79,8 +79,11 @@ def mirror_half_to_shifted(mag_half, n):
     mag_half = np.asarray(mag_half)
     if mag_half.shape[-1] != n // 2 + 1:
         raise ValueError("mag_half must have n//2+1 bins")
-    j = np.abs(np.arange(-(n // 2), (n + 1) // 2))
-    return np.ascontiguousarray(mag_half[..., j])
+    out = np.empty(mag_half.shape[:-1] + (n,), dtype=mag_half.dtype)
+    h = n // 2
+    out[..., :h] = mag_half[..., h:0:-1]               # i < n//2: bin n//2 - i (the negative frequencies)
+    out[..., h:] = mag_half[..., :(n + 1) // 2]        # i >= n//2: bin i - n//2
+    return out
 
 
 def shifted_index_of_bin(k, n):

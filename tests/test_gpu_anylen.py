@@ -52,3 +52,25 @@ def test_flags_any_length():
     assert magdb[100] == pytest.approx(20 * np.log10(n / 2), abs=1e-9)
     with pytest.raises(ValueError):
         fft_amd.fft_mag(np.zeros((2, 0)))
+
+
+def test_fused_chirp_z_kernel_agrees_with_the_kernel_chain():
+    """Up to 256 frames of n <= 4096 (non power of two) run the whole chirp-z in ONE kernel per frame (the GUI's calls:
+    five launches less); larger batches keep the kernel chain.  Same algorithm and tables; the compiler contracts the
+    multiply-adds differently in the two, so the spectra agree to a few ulp of the largest bin, not bit for bit."""
+    import fft_amd
+    rng = np.random.default_rng(77)
+    for n in (33, 100, 1500, 2000, 2049, 4095):
+        x = rng.standard_normal((300, n)) + np.sin(2 * np.pi * 0.07 * np.arange(n))
+        for kw in ({}, {"window": "blackman"}, {"db": True, "exclude_dc_nyq": True}):
+            chain = fft_amd.fft_mag(x, **kw)                      # 300 frames: kernel chain
+            fused = fft_amd.fft_mag(x[:7], **kw)                  # 7 frames: fused kernel
+            mf, pbf, pmf = fused
+            mc, pbc, pmc = chain
+            if kw.get("db"):
+                big = mc[:7] > mc[:7].max(axis=1, keepdims=True) - 100.0          # bins within 100 dB of the frame's peak
+                assert np.abs(mf - mc[:7])[big].max() < 1e-8
+            else:
+                assert (np.abs(mf - mc[:7]).max(axis=1) / mc[:7].max(axis=1)).max() < 1e-14
+            np.testing.assert_array_equal(pbf, pbc[:7])
+            np.testing.assert_allclose(pmf, pmc[:7], rtol=1e-13)
