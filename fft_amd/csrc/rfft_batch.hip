@@ -171,7 +171,7 @@ static int ilog2_exact(int64_t n) {
 }
 
 template <typename T>
-int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags, T* mag,
+int rfft_large_dev(const T* x, int64_t batch, int64_t frame_stride, int32_t n, int32_t window, double win_param, int32_t flags, T* mag,
                    int32_t* peak_bin, T* peak_mag, hipStream_t st);       // rfft_large.hip
 
 template <typename T>
@@ -195,9 +195,9 @@ int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32
     int log2n = 0;
     SA_TRY(check_args(x, batch, n, window, flags, mag, peak_bin, peak_mag, &log2n));
     if (batch == 0) return SA_OK;
-    // frames longer than one LDS-resident pass: the multi-pass path (rfft_large.hip; packed frames only)
-    if (log2n > (sizeof(T) == 8 ? 14 : 15) && (frame_stride <= 0 || frame_stride == n))
-        return rfft_large_dev<T>(x, batch, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
+    // frames longer than one LDS-resident pass: the multi-pass path (rfft_large.hip; packed or overlapping frames)
+    if (log2n > (sizeof(T) == 8 ? 14 : 15))
+        return rfft_large_dev<T>(x, batch, frame_stride, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
     const RfftPlan* p = get_rfft_plan(sizeof(T) == 8, n, window, win_param);
     if (!p) return SA_EHIP;
     RfftArgs<T> a;

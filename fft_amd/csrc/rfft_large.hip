@@ -38,7 +38,8 @@ struct RlCand { double m; int64_t k; };
 __device__ __forceinline__ bool rl_better(double m, int64_t k, double bm, int64_t bk) { return m > bm || (m == bm && k < bk); }
 
 template <typename T> struct RlArgs {
-    const T* x;               // [batch][n]
+    const T* x;               // frame b starts at x + b * frame_stride
+    int64_t frame_stride;     // n for packed frames, hop for overlapping (STFT) frames
     const T* win;             // [n] or nullptr
     cplx<T>* work;            // [batch][R1/2 + 1][S1]
     T* mag;                   // [batch][n/2 + 1] or nullptr
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * B)) rl_first_pass(RlAr
     auto load_group = [&](int64_t g) {
         const int64_t sg = g % gpf, b = g / gpf;
         const int64_t off = 2 * (sg * B + col);         // the pair's even column
-        const T* src = a.x + b * a.n + off;
+        const T* src = a.x + b * a.frame_stride + off;
         if (a.unaligned) {
 #pragma unroll
             for (int u = 0; u < P / R0; ++u)
@@ -466,9 +467,10 @@ static void rl_split(int L, int* l1, int* l2, int* l3) {
 // x, mag, peak_*: device.  Work memory (one buffer of (n/2 + S1) complex values per frame of a chunk + candidates) comes
 // from the calling thread's arena, so the call SYNCHRONISES `st` before it returns (the arena goes back idle).
 template <typename T>
-int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double win_param, int32_t flags, T* mag,
+int rfft_large_dev(const T* x, int64_t batch, int64_t frame_stride, int32_t n, int32_t window, double win_param, int32_t flags, T* mag,
                    int32_t* peak_bin, T* peak_mag, hipStream_t st) {
     SA_ENTER();
+    if (frame_stride <= 0) frame_stride = n;
     int L = 0;
     while ((1LL << L) < n) ++L;
     if (n < 32768 || (1LL << L) != n || L > RL_MAX_LOG2N) {
@@ -497,7 +499,8 @@ int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double 
     RlArgs<T> a{};
     a.n = n; a.win = dwin; a.flags = flags;
     a.db_floor = sizeof(T) == 8 ? (T)SA_DB_FLOOR_F64 : (T)SA_DB_FLOOR_F32;
-    a.unaligned = (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T))) != 0;
+    a.frame_stride = frame_stride;
+    a.unaligned = (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T))) != 0 || (frame_stride % 2) != 0;
     a.R1 = 1LL << l1; a.S1 = (int64_t)n >> l1;
     const int lf = l3 ? l3 : l2;                          // the last pass' row length
     a.R2 = l3 ? 1LL << l2 : 1; a.R3 = 1LL << lf;
@@ -542,7 +545,7 @@ int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double 
         hipStream_t s = ls[l];
         a.work = work[l]; a.cand = cand[l];
         a.batch = batch - b0 < chunk ? batch - b0 : chunk;
-        a.x = x + b0 * n;
+        a.x = x + b0 * frame_stride;
         a.mag = (flags & SA_F_WRITE_MAG) && mag ? mag + b0 * ((int64_t)n / 2 + 1) : nullptr;
         if ((rc = rl_set_twiddles(a, l1, n)) != SA_OK) break;
         if ((rc = rl_dispatch<T>(0, l1, a, s)) != SA_OK) break;
@@ -567,7 +570,7 @@ int rfft_large_dev(const T* x, int64_t batch, int32_t n, int32_t window, double 
     if (rc == SA_OK && e != hipSuccess) { set_error("rfft multi-pass path: %s", hipGetErrorString(e)); rc = SA_EHIP; }
     return rc;
 }
-template int rfft_large_dev<float>(const float*, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);
-template int rfft_large_dev<double>(const double*, int64_t, int32_t, int32_t, double, int32_t, double*, int32_t*, double*, hipStream_t);
+template int rfft_large_dev<float>(const float*, int64_t, int64_t, int32_t, int32_t, double, int32_t, float*, int32_t*, float*, hipStream_t);
+template int rfft_large_dev<double>(const double*, int64_t, int64_t, int32_t, int32_t, double, int32_t, double*, int32_t*, double*, hipStream_t);
 
 }  // namespace sa

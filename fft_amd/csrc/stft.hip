@@ -278,7 +278,7 @@ int stft_pcm16_dev(const int16_t* pcm, int64_t n_samples, int32_t channels, int3
     SA_ENTER();
     int lr = 0;
     while ((1 << lr) < nfft) ++lr;
-    if (nfft < 16 || (1 << lr) != nfft || nfft > 16384) { set_error("stft: nfft=%d must be a power of two in [16, 16384]", nfft); return SA_EUNSUP; }
+    if (nfft < 16 || (1 << lr) != nfft || nfft > (1 << 24)) { set_error("stft: nfft=%d must be a power of two in [16, 2^24]", nfft); return SA_EUNSUP; }
     if (hop < 1) { set_error("stft: hop must be >= 1"); return SA_EINVAL; }
     if (channels < 1) { set_error("stft: channels must be >= 1"); return SA_EINVAL; }
     if (window < SA_WIN_NONE || window > SA_WIN_LAST) { set_error("unknown window id %d", window); return SA_EINVAL; }

@@ -267,7 +267,8 @@ int sa_compute_f64(const sa_gen_params* p, int32_t window, double win_param, int
  * as in the reference's own import path (versão15.py:637).  The reference has no STFT.
  *   interleaved [n_samples][channels] int16
  *   mag         [channels][frames][nfft/2+1] float (SA_F_WRITE_MAG), peak_bin / peak_mag [channels][frames]
- * nfft: power of two 16..8192 (stereo fast path: both channels in one complex transform) or ..16384.
+ * nfft: power of two 16..8192 (stereo fast path: both channels in one complex transform) or ..2^24 (per-channel path;
+ *       above 32768 points the overlapping frames go through the multi-pass real FFT).
  * `scratch` (device variant): n_samples floats, only needed when channels != 2 or nfft > 8192. */
 int64_t sa_stft_num_frames(int64_t n_samples, int32_t nfft, int32_t hop);
 int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop,

@@ -43,6 +43,13 @@ def test_stft_stereo(nfft, hop):
     check(synth_pcm(nfft * 6 + 123, 2, nfft), nfft, hop, "blackman")
 
 
+@pytest.mark.parametrize("ch,nfft,hop", [(1, 1 << 16, 1 << 14), (2, 1 << 17, 30001), (1, 1 << 20, 1 << 19)])
+def test_stft_long_windows_take_the_multi_pass_path(ch, nfft, hop):
+    """nfft beyond one LDS-resident pass (> 32768): overlapping frames straight through the real-column four-step
+    (rfft_large.hip reads frame b at b * hop; an odd hop makes it load element-wise)."""
+    check(synth_pcm(nfft * 2 + hop + 11, ch, ch + 40), nfft, hop, "blackman")
+
+
 @pytest.mark.parametrize("ch", [1, 3])
 def test_stft_other_channel_counts(ch):
     check(synth_pcm(30000, ch, ch), 4096, 1024, "hann")
