@@ -5,6 +5,7 @@ sys.path.insert(0, ".")
 import torch
 import fft_amd
 from fft_amd import _lib
+from oracle import spectrum_oracle as O
 
 def main():
     sizes = [int(a) for a in sys.argv[1:]] or [16, 17, 18, 19, 20, 21, 22, 24]
@@ -19,8 +20,6 @@ def main():
             x = (np.sin(2 * np.pi * 0.1234 * np.arange(n)) + 0.1 * rng.standard_normal((batch, n))).astype(dtype)
             for win in ("none", "hann"):
                 mag, pb, pm = fft_amd.rfft_peak(x, win)
-                w = np.hanning(n + 1)[:0] if False else None
-                from oracle import spectrum_oracle as O
                 mref, pbref, pmref = O.rfft_mag_peak(x, win)
                 rel = np.sqrt(((mag - mref) ** 2).sum(axis=1) / (mref ** 2).sum(axis=1)).max()
                 mx = (np.abs(mag - mref).max(axis=1) / mref.max(axis=1)).max()
