@@ -1,7 +1,7 @@
 """Any-length spectra (sa_fft_mag_f64: Bluestein / power-of-two routes), host buffers: ms per frame.  python tools/bench_anylen.py [n ...]"""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import fft_amd
 
 for n in [int(a) for a in sys.argv[1:]] or [1000, 4099, 100000, 262146, 1000000, 1048576, 3000000]:

@@ -1,7 +1,7 @@
 """C1 latency split: the bare C-ABI call (preallocated numpy arrays) vs the Python shim around it, microseconds (median)."""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from fft_amd import _lib, specengine as S
 
 def med(fn, n=300, warm=30):

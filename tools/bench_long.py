@@ -2,7 +2,7 @@
 Prints ms per launch of 2^28 (f32) / 2^27 (f64) samples and the HBM-traffic model rate (14 or 22 bytes per fp32 sample)."""
 import sys, json, time, ctypes as C
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from fft_amd import _lib
 

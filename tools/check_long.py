@@ -1,7 +1,7 @@
 """Long-frame rfft (rfft_large.hip): error against numpy and time per size.  python tools/check_long.py [log2n ...]"""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import fft_amd
 from fft_amd import _lib
