@@ -88,6 +88,32 @@ template <typename T, int R, typename C> __device__ __forceinline__ void bfly(C*
 __device__ __forceinline__ float mag_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
 __device__ __forceinline__ double mag_sqrt(double v) { return sqrt(v); }
 
+// Wave-wide reductions on the VALU cross-lane path (DPP), result in every lane: 6 dependent VALU ops
+// instead of 6 LDS-latency ds_bpermute round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned old, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    unsigned u = __float_as_uint(v);     // non-negative floats order like unsigned integers
+    u = max(u, dpp_u32<0x111, 0xF>(u, u));   // row_shr:1
+    u = max(u, dpp_u32<0x112, 0xF>(u, u));   // row_shr:2
+    u = max(u, dpp_u32<0x114, 0xF>(u, u));   // row_shr:4
+    u = max(u, dpp_u32<0x118, 0xF>(u, u));   // row_shr:8   -> lane 15 of each row holds the row max
+    u = max(u, dpp_u32<0x142, 0xA>(u, u));   // row_bcast:15 into rows 1 and 3
+    u = max(u, dpp_u32<0x143, 0xC>(u, u));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the max
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u, 63));
+}
+__device__ __forceinline__ int wave_min_u32(unsigned u) {
+    u = min(u, dpp_u32<0x111, 0xF>(u, u));
+    u = min(u, dpp_u32<0x112, 0xF>(u, u));
+    u = min(u, dpp_u32<0x114, 0xF>(u, u));
+    u = min(u, dpp_u32<0x118, 0xF>(u, u));
+    u = min(u, dpp_u32<0x142, 0xA>(u, u));
+    u = min(u, dpp_u32<0x143, 0xC>(u, u));
+    return __builtin_amdgcn_readlane((int)u, 63);
+}
+
 // LDS index with two-level padding: one pad element per 2^S elements and one more per 2^(2S).
 // Makes every power-of-two element stride conflict free for the wide DS reads (bank rows hold 2^S
 // elements: S=5 for 8-byte float2, S=4 for 16-byte double2).

@@ -198,13 +198,22 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
         };
         if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});
         // reduce (best, best_k) over the TPF threads of this frame
-        constexpr int WREDUCE = TPF < 64 ? TPF : 64;
+        if constexpr (sizeof(T) == 4 && TPF >= 64) {
+            // whole waves per frame, fp32: wave maximum and the lowest bin among the lanes that hold it on the DPP path
+            // (6 dependent VALU ops each instead of 6 ds_bpermute round trips).  A lane whose bins were all NaN still
+            // carries -1: it enters as 0 with no bin, so it can neither win nor name a bin.
+            const float wb = wave_max_f32(fmaxf((float)best, 0.0f));
+            best_k = wave_min_u32((float)best == wb ? (unsigned)best_k : 0x7fffffffu);
+            best = best_k == 0x7fffffff ? (T)-1 : (T)wb;
+        } else {
+            constexpr int WREDUCE = TPF < 64 ? TPF : 64;
 #pragma unroll
-        for (int off = WREDUCE / 2; off > 0; off >>= 1) {
-            const T om = __shfl_xor(best, off);
-            const int ok = __shfl_xor(best_k, off);
-            const bool tk = peak_better(om, ok, best, best_k);
-            best = tk ? om : best; best_k = tk ? ok : best_k;
+            for (int off = WREDUCE / 2; off > 0; off >>= 1) {
+                const T om = __shfl_xor(best, off);
+                const int ok = __shfl_xor(best_k, off);
+                const bool tk = peak_better(om, ok, best, best_k);
+                best = tk ? om : best; best_k = tk ? ok : best_k;
+            }
         }
         if constexpr (TPF > 64) {
             const int wave = threadIdx.x >> 6;

@@ -190,14 +190,23 @@ stft_stereo_kernel(StftArgs a) {
             }
         };
         if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});
-        constexpr int WRED = TPF < 64 ? TPF : 64;
+        if constexpr (TPF >= 64) {
+            // whole waves per frame: wave maximum and the lowest bin among the lanes that hold it, on the DPP path
+            // (magnitudes are >= 0 and never NaN here: int16 samples times a finite window)
+            const float wl = wave_max_f32(bl), wr = wave_max_f32(br);
+            kl = wave_min_u32(bl == wl ? (unsigned)kl : 0x7fffffffu);
+            kr = wave_min_u32(br == wr ? (unsigned)kr : 0x7fffffffu);
+            bl = wl; br = wr;
+        } else {
+            constexpr int WRED = TPF;
 #pragma unroll
-        for (int off = WRED / 2; off > 0; off >>= 1) {
-            const float ol = __shfl_xor(bl, off), orr = __shfl_xor(br, off);
-            const int okl = __shfl_xor(kl, off), okr = __shfl_xor(kr, off);
-            const bool tl_ = (ol > bl) | ((ol == bl) & (okl < kl)), tr_ = (orr > br) | ((orr == br) & (okr < kr));
-            bl = tl_ ? ol : bl; kl = tl_ ? okl : kl;
-            br = tr_ ? orr : br; kr = tr_ ? okr : kr;
+            for (int off = WRED / 2; off > 0; off >>= 1) {
+                const float ol = __shfl_xor(bl, off), orr = __shfl_xor(br, off);
+                const int okl = __shfl_xor(kl, off), okr = __shfl_xor(kr, off);
+                const bool tl_ = (ol > bl) | ((ol == bl) & (okl < kl)), tr_ = (orr > br) | ((orr == br) & (okr < kr));
+                bl = tl_ ? ol : bl; kl = tl_ ? okl : kl;
+                br = tr_ ? orr : br; kr = tr_ ? okr : kr;
+            }
         }
         if constexpr (TPF > 64) {
             constexpr int WPF = TPF / 64;           // waves per frame
