@@ -74,3 +74,42 @@ def test_fused_chirp_z_kernel_agrees_with_the_kernel_chain():
                 assert (np.abs(mf - mc[:7]).max(axis=1) / mc[:7].max(axis=1)).max() < 1e-14
             np.testing.assert_array_equal(pbf, pbc[:7])
             np.testing.assert_allclose(pmf, pmc[:7], rtol=1e-13)
+
+
+def test_small_call_routes_agree_across_processes(tmp_path):
+    """The GUI-sized calls take the zero-copy staging route and the one-kernel chirp-z by default; a second process with both
+    switched off (SA_ZEROCOPY_MAX=0, SA_BLU_FUSED=0: device copies + kernel chain) must return the same spectra, samples and
+    peaks for the same calls."""
+    import os
+    import subprocess
+    import sys
+    import fft_amd
+    from fft_amd import specengine as S
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import fft_amd\n"
+        "from fft_amd import specengine as S\n"
+        "rng = np.random.default_rng(5)\n"
+        "out = {}\n"
+        "for n in (1500, 2000, 4096):\n"
+        "    y = rng.standard_normal(n) + np.sin(2 * np.pi * 0.11 * np.arange(n))\n"
+        "    m, pb, pm = fft_amd.fft_mag(y, 'hann')\n"
+        "    out[f'm{n}'] = m; out[f'pb{n}'] = pb; out[f'pm{n}'] = pm\n"
+        "p = S.validate_inputs(0.02, 10e3, 100e3, 10.0, 'Seno')\n"
+        "d = S.compute(p, 2.0)\n"
+        "out['cy'] = d['y']; out['cY'] = d['Y']; out['ct'] = d['t']\n"
+        "np.savez(sys.argv[1], **out)\n")
+    files = {}
+    for tag, env in (("dflt", {}), ("off", {"SA_ZEROCOPY_MAX": "0", "SA_BLU_FUSED": "0"})):
+        f = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        files[tag] = np.load(f)
+    a, b = files["dflt"], files["off"]
+    for n in (1500, 2000, 4096):
+        assert np.abs(a[f"m{n}"] - b[f"m{n}"]).max() / b[f"m{n}"].max() < 1e-14
+        assert a[f"pb{n}"] == b[f"pb{n}"] and abs(a[f"pm{n}"] - b[f"pm{n}"]) <= 1e-13 * abs(b[f"pm{n}"])
+    np.testing.assert_array_equal(a["cy"], b["cy"]); np.testing.assert_array_equal(a["ct"], b["ct"])
+    assert np.abs(a["cY"] - b["cY"]).max() / b["cY"].max() < 1e-14
