@@ -289,7 +289,9 @@ def case_long(rng):
         return desc, "peak bins differ beyond ties"
     scale = np.maximum(np.maximum(mref.max(axis=1), 1e-2 * xmax), 1e-300)[:, None]
     err = (np.abs(mag.astype(np.float64) - mref) / scale).max()
-    if err > (2e-6 if dtype == np.float32 else 1e-12):
+    # fp32 frames are transformed in fp32 (like the one-pass kernels): the worst bin error grows with the frame's largest
+    # magnitude times ~eps log2 n (2.1e-6 seen at n = 2^22 on an on-bin tone); the north-star bar is 1e-5 log2 n relative L2
+    if err > (2.5e-7 * np.log2(n) if dtype == np.float32 else 1e-12):
         return desc, f"error {err:.3g} relative to the row maximum"
     return desc, None
 
