@@ -372,10 +372,13 @@ template <typename T> static int rl_set_twiddles(RlArgs<T>& a, int lr, int64_t m
 template <typename T> struct RlShape {
     static constexpr bool F = sizeof(T) == 4;
     static constexpr int BC = F ? 16 : 8;
-    static constexpr int pp_first(int lr) { return F && lr >= 8 ? 16 : 8; }
-    static constexpr int pp_mid(int lr) { return F && lr >= 9 ? 16 : 8; }
-    static constexpr int pp_final(int lr) { return F ? (lr == 8 || lr == 10 ? 16 : 8) : (lr == 8 || lr == 9 ? 16 : 8); }
-    static constexpr int bf(int lr) { return F ? (lr <= 8 ? 32 : lr == 9 ? 8 : 16) : (lr <= 8 ? 16 : 8); }   // rows, last pass
+    // 1024-point passes (only 2^28 / 2^29 need them): 8 points per thread and half the columns, or the 1024-thread
+    // workgroup's 128-register budget spills (first pass fp32: 210 spilled registers, 2.68 -> 1.37 ms per 2^28 samples)
+    static constexpr int bc(int lr) { return lr == 10 ? BC / 2 : BC; }
+    static constexpr int pp_first(int lr) { return F && lr >= 8 && lr <= 9 ? 16 : 8; }
+    static constexpr int pp_mid(int lr) { return F && lr == 9 ? 16 : 8; }
+    static constexpr int pp_final(int lr) { return F ? (lr == 8 ? 16 : 8) : (lr == 8 || lr == 9 ? 16 : 8); }
+    static constexpr int bf(int lr) { return F ? (lr <= 8 ? 32 : 8) : (lr <= 8 ? 16 : lr == 9 ? 8 : 4); }   // rows, last pass
 };
 
 template <typename T, int LR, int PP, int B> static int rl_launch_first(const RlArgs<T>& a, hipStream_t st) {
@@ -416,10 +419,10 @@ template <typename T, int LR, int PP, int B> static int rl_launch_final(const Rl
     return SA_OK;
 }
 template <typename T, int LR> static int rl_run_first(const RlArgs<T>& a, hipStream_t st) {
-    return rl_launch_first<T, LR, RlShape<T>::pp_first(LR), RlShape<T>::BC>(a, st);
+    return rl_launch_first<T, LR, RlShape<T>::pp_first(LR), RlShape<T>::bc(LR)>(a, st);
 }
 template <typename T, int LR> static int rl_run_mid(const RlArgs<T>& a, hipStream_t st) {
-    return rl_launch_mid<T, LR, RlShape<T>::pp_mid(LR), RlShape<T>::BC>(a, st);
+    return rl_launch_mid<T, LR, RlShape<T>::pp_mid(LR), RlShape<T>::bc(LR)>(a, st);
 }
 template <typename T, int LR> static int rl_run_final(const RlArgs<T>& a, hipStream_t st) {
     return rl_launch_final<T, LR, RlShape<T>::pp_final(LR), RlShape<T>::bf(LR)>(a, st);
@@ -448,7 +451,7 @@ constexpr int RL_MAX_LOG2N = 29;
 static void rl_split(int L, int* l1, int* l2, int* l3) {
     // a 1024-point FIRST pass (one 140 KiB workgroup per CU, 1024 x 128-byte reads each) runs at a quarter of the others'
     // rate, so 2^19 and 2^20 take three short passes instead: measured 1.49 / 1.52 ms per 2^28 samples against 2.79 / 3.10
-    // (the 1024-point kernels spill registers; 2^28 and 2^29 need one / two of them and keep them out of pass 1)
+    // (2^28 and 2^29 need one / two 1024-point factors and keep them out of pass 1)
     if (L <= 18) { *l1 = (L + 1) / 2; *l2 = L - *l1; *l3 = 0; }
     else {
         *l1 = (L + 2) / 3 < 9 ? (L + 2) / 3 : 9;
