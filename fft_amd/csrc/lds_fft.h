@@ -12,15 +12,23 @@
 
 namespace sa {
 
-// Pass plan: with P = 8 points per thread radix-8 passes then one 4 or 2; with P = 16 radix-16 passes
-// then one 8, 4 or 2 (fewer LDS exchanges and barriers for the long transforms).
+// Pass plan: with P = 8 points per thread radix-8 passes and one 4 or 2; with P = 16 radix-16 passes
+// and one 8, 4 or 2 (fewer LDS exchanges and barriers for the long transforms).
+// Where the small pass goes: the twiddles that follow a radix-r pass cost (P - P/r) products plus the r - 2 that
+// derive the powers of the thread's base factor, and the last pass has none.  With the small pass LAST a
+// full-radix pass pays 15 + 14 complex products for nothing; with 16 points per thread and four passes it runs
+// SECOND instead (8192 = 16 * 2 * 16 * 16: 8 products in place of 29, -84 VALU instructions per thread and
+// transform).  There M_1 >= 256, so its LDS gathers are lane-contiguous, and the passes after it read with M_j = 16
+// and 1, both conflict free under the paddings below.  Three-pass plans and P = 8 keep the small pass last: moved
+// forward its gather would run at M_j = 16 or 8 with two lanes per bank.
 template <int LR, int PP = 8> struct FftPlan {
     static constexpr int R = 1 << LR;
     static constexpr int LB = PP == 16 ? 4 : 3;                // log2 of the main radix
     static constexpr int NB = LR / LB;
     static constexpr int REM = LR % LB;
     static constexpr int NP = NB + (REM ? 1 : 0);
-    static constexpr int radix(int j) { return j < NB ? (1 << LB) : (1 << REM); }
+    static constexpr int JREM = !REM ? -1 : (PP == 16 && NB >= 3) ? 1 : NB;      // position of the small pass
+    static constexpr int radix(int j) { return j == JREM ? (1 << REM) : (1 << LB); }
     static constexpr int H(int j) { int h = 1; for (int i = 0; i < j; ++i) h *= radix(i); return h; }
     static constexpr int P = LR >= LB ? PP : R;                // points per thread
     static constexpr int TPF = R / P;                          // threads per transform
@@ -40,6 +48,8 @@ template <typename T, int LR, int PP> constexpr int exch_pad_mult(int j) {      
     using PL = FftPlan<LR, PP>;
     if (sizeof(cplx<T>) != 8 || j < 1 || j >= PL::NP) return 1;
     const int mj = PL::R / PL::H(j) / PL::radix(j);
+    // (no padding at all for the lane-contiguous exchange around a small second pass, so that butterfly legs pair
+    // up in ds_read2st64 / ds_write2st64: 16 fewer LDS instructions per thread, measured 0.8 % SLOWER on C3)
     return (PL::radix(j) == 16 && mj >= 2 && mj <= 16) ? 2 : 1;
 }
 template <int S, int MULT> __device__ __forceinline__ int lds_pad_m(int a) { return a + MULT * (a >> S) + (a >> (2 * S)); }
@@ -97,7 +107,7 @@ template <typename T> struct TwLds {
 };
 template <typename T, int LR, int PP = 8> struct TwRegs {
     using PL = FftPlan<LR, PP>;
-    static_assert(PL::NP == 1 || PL::P == PL::radix(0), "one butterfly per thread in the twiddled passes");
+    static_assert(PL::NP == 1 || PL::P == PL::radix(0), "one butterfly per thread in the first pass");
     cplx<T> w[PL::NP > 1 ? PL::NP - 1 : 1];
     __device__ __forceinline__ void load(const cplx<T>* __restrict__ twR, int tl) {
 #pragma unroll
@@ -124,10 +134,12 @@ __device__ __forceinline__ void lds_fft_pass(cplx<T>* v, cplx<T>* buf, int tl, c
         // being hoisted out of the caller's frame loop, where they would pin ~16 VGPRs per pass
         asm volatile("" : "+v"(tl));
         // the pass' twiddles are requested BEFORE the barrier so their L2 latency overlaps the wait
-        cplx<T> w[P / Rj];
+        // (a thread's butterflies tl + TPF u share one factor whenever M_j divides TPF)
+        constexpr int NWJ = TPF % Mj == 0 ? 1 : P / Rj;
+        cplx<T> w[NWJ];
         if constexpr (Mj > 1) {
 #pragma unroll
-            for (int u = 0; u < P / Rj; ++u) w[u] = tw.template get<J, Hprev, Mj>(tl + TPF * u);
+            for (int u = 0; u < NWJ; ++u) w[u] = tw.template get<J, Hprev, Mj>(tl + TPF * u);
         }
         // Padded addresses are additive over disjoint bit fields of the index (see lds_pad_split below):
         // one base per pass from the lane index, everything else is a compile-time offset.
@@ -142,7 +154,7 @@ __device__ __forceinline__ void lds_fft_pass(cplx<T>* v, cplx<T>* buf, int tl, c
 #pragma unroll
             for (int n = 0; n < Rj; ++n) v[u * Rj + n] = rd[lds_pad_mc<S, MR>(cu + n * Mj)];
             bfly<T, Rj>(&v[u * Rj]);
-            if constexpr (Mj > 1) apply_twiddle_powers<T, Rj>(&v[u * Rj], w[u]);
+            if constexpr (Mj > 1) apply_twiddle_powers<T, Rj>(&v[u * Rj], w[u % NWJ]);
         }
         __syncthreads();
 #pragma unroll
