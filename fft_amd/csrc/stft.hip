@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "lds_fft.h"
+#include "lds_fft_tail2.h"
 #include "runtime.h"
 
 namespace sa {
@@ -84,8 +85,11 @@ stft_stereo_kernel(StftArgs a) {
 #pragma unroll
         for (int i = 0; i < P; ++i) w[i] = 0.5f / 32768.0f;
     }
+    // nfft 8192, one frame per workgroup: the last radix-2 pass is folded into the epilogue (lds_fft_tail2.h)
+    constexpr bool T2 = LR == 13 && PP == 16 && FPW == 1;
     TwRegs<float, LR, PP> tw;
-    tw.load(a.twR, tl);
+    FftTail2_8192 tw2;
+    if constexpr (T2) tw2.load(a.twR, tl); else tw.load(a.twR, tl);
     const uint32_t* pcm = reinterpret_cast<const uint32_t*>(a.pcm);   // one (L,R) pair per dword
     uint32_t raw[P];
     // Frame loads / spectrum stores go through buffer descriptors: one 32-bit lane offset per access family plus
@@ -134,7 +138,8 @@ stft_stereo_kernel(StftArgs a) {
             const int64_t nb_ = base + slot_step * FPW + g;                     // next round's frame (clamped, L2-hot, unused at the end)
             load_frame(nb_ <= last ? nb_ : last, tq);
         }
-        lds_fft_tw<float, LR, PP>(v, buf, tl, tw);
+        if constexpr (T2) { tw2.run(v, buf, tl); __syncthreads(); }
+        else lds_fft_tw<float, LR, PP>(v, buf, tl, tw);
         // ---- split channels, magnitudes, peaks ------------------------------------------------------
         // pair q < N/2 ... thread 0 adds bin N/2 (rows are NB floats; stores past a row are dropped by
         // the descriptor's range check, a zero-length descriptor drops them all)
@@ -151,9 +156,11 @@ stft_stereo_kernel(StftArgs a) {
             FPW == 1 && st_ok ? rowr : nullptr, 0, FPW == 1 && st_ok ? NB * 4 : 0, 0x00020000);
         // The dB conversion is a uniform run-time choice: two instantiations of the epilogue behind one scalar
         // branch (as a select, every output would pay the logarithm whether it is wanted or not).
+        float bl2 = -1.f, br2 = -1.f;                   // T2: second pair of trackers, bins visited in DEscending order
+        int kl2 = 0x7fffffff, kr2 = 0x7fffffff;
         auto epilogue = [&](auto DBT) {
             constexpr bool DB = decltype(DBT)::value;
-            auto emit = [&](int q, int voff, int soff, float2 zq, float2 zm) {
+            auto emit = [&](int q, int voff, int soff, float2 zq, float2 zm, auto DESC) {
                 const float2 L = mk<float>(zq.x + zm.x, zq.y - zm.y);          // the 1/2 is in the window
                 const float2 Rr = mk<float>(zq.y + zm.y, zm.x - zq.x);
                 const float mL = mag_sqrt(L.x * L.x + L.y * L.y), mR = mag_sqrt(Rr.x * Rr.x + Rr.y * Rr.y);
@@ -166,10 +173,53 @@ stft_stereo_kernel(StftArgs a) {
                     if (st_ok) { rowl[q] = oL; rowr[q] = oR; }
                 }
                 const bool ok = !(excl && (q == 0 || q == N / 2));
-                const bool gl = ok & (mL > bl), gr = ok & (mR > br);     // q ascending per thread: first max kept with '>'
-                bl = gl ? mL : bl; kl = gl ? q : kl;
-                br = gr ? mR : br; kr = gr ? q : kr;
+                if constexpr (decltype(DESC)::value) {                   // q descending: the lowest of equal maxima with '>='
+                    const bool gl = ok & (mL >= bl2), gr = ok & (mR >= br2);
+                    bl2 = gl ? mL : bl2; kl2 = gl ? q : kl2;
+                    br2 = gr ? mR : br2; kr2 = gr ? q : kr2;
+                } else {
+                    const bool gl = ok & (mL > bl), gr = ok & (mR > br);     // q ascending per thread: first max kept with '>'
+                    bl = gl ? mL : bl; kl = gl ? q : kl;
+                    br = gr ? mR : br; kr = gr ? q : kr;
+                }
             };
+            if constexpr (T2) {
+                // Legs of the final radix-2 butterflies: Z[q] = E[q] + O[q], Z[q + N/2] = E[q] - O[q] (q < N/2).  A thread
+                // takes butterflies q = tq + TPF u < N/4 and their mirrors N/2 - q: bin q pairs Z[q] with
+                // Z[N - q] = E[N/2 - q] - O[N/2 - q], bin N/2 - q pairs Z[N/2 - q] = E + O (mirror) with Z[N/2 + q] = E[q] - O[q].
+                // Mirror address as below: pad(TPF - tq) + a constant, lane 0 a constant of its own; lane 0's q = 0 is its
+                // own mirror and yields bins 0 (Z[0], Z[0]) and N/2 (Z[N/2], Z[N/2]).
+                constexpr int H = N / 2, PLANE = FftTail2_8192::PLANE;
+                const float2* pe = buf + lds_pad<S>(tq);
+                const int mlow = lds_pad<S>(TPF - tq);
+#pragma unroll
+                for (int u = 0; u < (H / 2) / TPF; ++u) {
+                    const int q = tq + TPF * u;
+                    const int moff = lds_pad_c<S>(H - TPF * (u + 1));
+                    const int m0 = lds_pad_c<S>((H - TPF * u) & (H - 1)) - moff;
+                    const int ml = (tq == 0 ? m0 : mlow) + moff;
+                    const float2 eq = pe[lds_pad_c<S>(TPF * u)], oq = pe[PLANE + lds_pad_c<S>(TPF * u)];
+                    const float2 em = buf[ml], om = buf[PLANE + ml];
+                    float2 zq = cadd(eq, oq), zm = csub(em, om), yq = cadd(em, om), ym = csub(eq, oq);
+                    if (u == 0) {                                   // q = 0: (zq, zm, yq, ym) = (S, D, S, D) -> (S, S), (D, D)
+                        const bool z0 = tq == 0;
+                        const float2 t = zm;
+                        zm.x = z0 ? yq.x : zm.x; zm.y = z0 ? yq.y : zm.y;
+                        yq.x = z0 ? t.x : yq.x;  yq.y = z0 ? t.y : yq.y;
+                    }
+                    emit(q, tq * 4, TPF * u * 4, zq, zm, std::false_type{});
+                    emit(H - q, (TPF - tq) * 4, (H - TPF * (u + 1)) * 4, yq, ym, std::true_type{});
+                }
+                if (tq == 0) {                                      // bin N/4: butterfly N/4 is its own mirror
+                    const float2 e = buf[lds_pad_c<S>(H / 2)], o = buf[PLANE + lds_pad_c<S>(H / 2)];
+                    emit(H / 2, 0, (H / 2) * 4, cadd(e, o), csub(e, o), std::true_type{});
+                }
+                // the ascending trackers hold bins < N/4, the descending ones bins >= N/4
+                const bool tl_ = bl2 > bl, tr_ = br2 > br;
+                bl = tl_ ? bl2 : bl; kl = tl_ ? kl2 : kl;
+                br = tr_ ? br2 : br; kr = tr_ ? kr2 : kr;
+                return;
+            }
             // Padded LDS addresses are additive over disjoint bit fields (lds_fft.h): Z[q], q = tq + TPF u, sits at
             // pad(tq) + pad(TPF u); its mirror N - q = (N - TPF (u+1)) + (TPF - tq) at pad(TPF - tq) + a constant for
             // every lane but tq = 0 (whose mirror N - TPF u is a constant itself) — one select instead of the
@@ -182,11 +232,11 @@ stft_stereo_kernel(StftArgs a) {
                 const int moff = lds_pad_c<S>(N - TPF * (u + 1));
                 const int m0 = lds_pad_c<S>((N - TPF * u) & (N - 1)) - moff;       // what tq = 0 needs in place of mlow
                 const int ml = tq == 0 ? m0 : mlow;
-                emit(q, tq * 4, TPF * u * 4, pq[lds_pad_c<S>(TPF * u)], buf[ml + moff]);
+                emit(q, tq * 4, TPF * u * 4, pq[lds_pad_c<S>(TPF * u)], buf[ml + moff], std::false_type{});
             }
             if (tq == 0) {
                 const float2 z = buf[lds_pad_c<S>(N / 2)];
-                emit(N / 2, 0, (N / 2) * 4, z, z);
+                emit(N / 2, 0, (N / 2) * 4, z, z, std::false_type{});
             }
         };
         if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});

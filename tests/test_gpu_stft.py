@@ -101,7 +101,12 @@ def test_stft_edges():
     pcm = np.zeros((8192, 2), np.int16); pcm[:, 0] = 16384                          # exactly one frame; DC on L, silence on R
     mag, pb, pm = fft_amd.stft_pcm16(pcm, 8192, 2048, "none")
     assert mag.shape == (2, 1, 4097) and pb[0, 0] == 0 and pm[0, 0] == pytest.approx(4096.0, rel=1e-6)
-    assert mag[1].max() == 0.0
+    assert mag[1].max() == 0.0 and pb[1, 0] == 0                                    # all bins tie: the first one is named
+    for nfft in (8192, 4096, 512):                                                   # ties across threads, waves and trackers
+        _, pbs, _ = fft_amd.stft_pcm16(np.zeros((nfft + nfft // 4, 2), np.int16), nfft, nfft // 4, "hann")
+        assert (pbs == 0).all()
+        _, pbs, _ = fft_amd.stft_pcm16(np.zeros((nfft + nfft // 4, 2), np.int16), nfft, nfft // 4, "hann", exclude_dc_nyq=True)
+        assert (pbs == 1).all()
     with pytest.raises(ValueError):
         fft_amd.stft_pcm16(np.zeros((5000, 2), np.int16), 1000, 250)                # nfft not a power of two
     with pytest.raises(ValueError):
