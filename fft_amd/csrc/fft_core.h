@@ -89,28 +89,30 @@ __device__ __forceinline__ float mag_sqrt(float v) { return __builtin_amdgcn_sqr
 __device__ __forceinline__ double mag_sqrt(double v) { return sqrt(v); }
 
 // Wave-wide reductions on the VALU cross-lane path (DPP), result in every lane: 6 dependent VALU ops
-// instead of 6 LDS-latency ds_bpermute round trips.
+// instead of 6 LDS-latency ds_bpermute round trips.  Lanes a DPP step does not reach receive `old`; passing the
+// operation's IDENTITY there (0 for max, ~0 for min) is what lets the compiler fold the move into the max / min
+// itself (v_max_u32_dpp: one instruction per step instead of copy + v_mov_dpp + max).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_u32(unsigned old, unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
     unsigned u = __float_as_uint(v);     // non-negative floats order like unsigned integers
-    u = max(u, dpp_u32<0x111, 0xF>(u, u));   // row_shr:1
-    u = max(u, dpp_u32<0x112, 0xF>(u, u));   // row_shr:2
-    u = max(u, dpp_u32<0x114, 0xF>(u, u));   // row_shr:4
-    u = max(u, dpp_u32<0x118, 0xF>(u, u));   // row_shr:8   -> lane 15 of each row holds the row max
-    u = max(u, dpp_u32<0x142, 0xA>(u, u));   // row_bcast:15 into rows 1 and 3
-    u = max(u, dpp_u32<0x143, 0xC>(u, u));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the max
+    u = max(u, dpp_u32<0x111, 0xF>(0u, u));   // row_shr:1
+    u = max(u, dpp_u32<0x112, 0xF>(0u, u));   // row_shr:2
+    u = max(u, dpp_u32<0x114, 0xF>(0u, u));   // row_shr:4
+    u = max(u, dpp_u32<0x118, 0xF>(0u, u));   // row_shr:8   -> lane 15 of each row holds the row max
+    u = max(u, dpp_u32<0x142, 0xA>(0u, u));   // row_bcast:15 into rows 1 and 3
+    u = max(u, dpp_u32<0x143, 0xC>(0u, u));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the max
     return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u, 63));
 }
 __device__ __forceinline__ int wave_min_u32(unsigned u) {
-    u = min(u, dpp_u32<0x111, 0xF>(u, u));
-    u = min(u, dpp_u32<0x112, 0xF>(u, u));
-    u = min(u, dpp_u32<0x114, 0xF>(u, u));
-    u = min(u, dpp_u32<0x118, 0xF>(u, u));
-    u = min(u, dpp_u32<0x142, 0xA>(u, u));
-    u = min(u, dpp_u32<0x143, 0xC>(u, u));
+    u = min(u, dpp_u32<0x111, 0xF>(~0u, u));
+    u = min(u, dpp_u32<0x112, 0xF>(~0u, u));
+    u = min(u, dpp_u32<0x114, 0xF>(~0u, u));
+    u = min(u, dpp_u32<0x118, 0xF>(~0u, u));
+    u = min(u, dpp_u32<0x142, 0xA>(~0u, u));
+    u = min(u, dpp_u32<0x143, 0xC>(~0u, u));
     return __builtin_amdgcn_readlane((int)u, 63);
 }
 

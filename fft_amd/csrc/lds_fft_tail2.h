@@ -21,10 +21,17 @@ struct FftTail2_8192 {
     static_assert(2 * PLANE <= lds_fft_elems<float, LR>(), "leg planes fit the transform's buffer");
     // leg n of butterfly q sits at buf[n * PLANE + lds_pad<S>(q)]
 
-    float2 w0, w1;                       // w_8192^tl, w_512^(tl % 32): per-thread constants of a launch
-    __device__ __forceinline__ void load(const float2* __restrict__ twR, int tl) {
+    // The second pass' twiddles w_512^(m k), m = tl % 32, are read from a table in LDS, [k][m] so that the 32 lanes of
+    // a half-wave read one contiguous row: 15 ds_reads in place of the 14-product power tree (56 VALU instructions;
+    // the exchanges of this plan leave the LDS pipe about half idle, the VALU none).
+    static constexpr int TAB = 15 * 32;  // float2 elements
+    float2 w0;                           // w_8192^tl: per-thread constant of a launch
+    const float2* tab;                   // + 32 (k - 1): w_512^(m k)
+    // all threads of the workgroup; the caller's next barrier publishes the table
+    __device__ __forceinline__ void load(const float2* __restrict__ twR, int tl, float2* lds_tab) {
         w0 = twR[tl & 511];
-        w1 = twR[16 * (tl & 31)];
+        if (tl < TAB) lds_tab[tl] = twR[(16 * (tl & 31) * ((tl >> 5) + 1)) & (R - 1)];
+        tab = lds_tab + (tl & 31);
     }
     static __device__ __forceinline__ float2 opaque(float2 c) {      // see TwRegs::get
         asm volatile("" : "+v"(c.x), "+v"(c.y));
@@ -52,7 +59,8 @@ struct FftTail2_8192 {
 #pragma unroll
             for (int n = 0; n < 16; ++n) v[n] = rd[lds_pad_mc<S, 1>(32 * n)];
             bfly16<float>(v);
-            apply_twiddle_powers<float, 16>(v, opaque(w1));
+#pragma unroll
+            for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tab[32 * (k - 1)]);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; ++k) wr[lds_pad_mc<S, 1>(512 * k)] = v[k];
@@ -67,6 +75,10 @@ struct FftTail2_8192 {
 #pragma unroll
             for (int n = 0; n < 16; ++n) v[n] = rd[2 * n];
             bfly16<float>(v);
+            // element id + 512 k is leg id % 2 of final butterfly q = id / 2 + 256 k = lo + 256 k.
+            // The barrier and the stores are written in BOTH arms of the (wave-uniform) branch, in opposite order of k so
+            // that the compiler does not sink them below it: joined after the branch, the products would have to be
+            // moved back into the registers the other arm left its values in (25 moves).
             if (__builtin_amdgcn_readfirstlane(half)) {          // odd butterflies: v[k] *= w_32^k
                 constexpr float c[16] = {1.f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
                                          0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
@@ -78,11 +90,14 @@ struct FftTail2_8192 {
                     if (k == 8) v[k] = mul_mi(v[k]);
                     else v[k] = cmul(v[k], mk<float>(c[k], -c[k < 8 ? 8 - k : k - 8]));      // sin x = cos(x - pi/2)
                 }
-            }
-            __syncthreads();
-            // element id + 512 k is leg id % 2 of final butterfly q = id / 2 + 256 k = lo + 256 k
+                __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; ++k) wr[lds_pad_c<S>(256 * k)] = v[k];
+                for (int k = 15; k >= 0; --k) wr[lds_pad_c<S>(256 * k)] = v[k];
+            } else {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wr[lds_pad_c<S>(256 * k)] = v[k];
+            }
         }
     }
 };

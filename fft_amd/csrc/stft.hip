@@ -89,7 +89,7 @@ stft_stereo_kernel(StftArgs a) {
     constexpr bool T2 = LR == 13 && PP == 16 && FPW == 1;
     TwRegs<float, LR, PP> tw;
     FftTail2_8192 tw2;
-    if constexpr (T2) tw2.load(a.twR, tl); else tw.load(a.twR, tl);
+    if constexpr (T2) tw2.load(a.twR, tl, reinterpret_cast<float2*>(red_k + 2 * NW)); else tw.load(a.twR, tl);
     const uint32_t* pcm = reinterpret_cast<const uint32_t*>(a.pcm);   // one (L,R) pair per dword
     uint32_t raw[P];
     // Frame loads / spectrum stores go through buffer descriptors: one 32-bit lane offset per access family plus
@@ -305,7 +305,8 @@ template <int LR, int PP>
 static int launch_stereo_pp(const StftArgs& a, hipStream_t st) {
     constexpr int FPW = stft_fpw<LR, PP>();
     constexpr int NW = (FftPlan<LR, PP>::TPF * FPW + 63) / 64;
-    constexpr int lds = FPW * lds_fft_elems<float, LR>() * 8 + NW * 16 + 16;
+    constexpr int lds = FPW * lds_fft_elems<float, LR>() * 8 + NW * 16 + 16 +
+                        (LR == 13 && PP == 16 && FPW == 1 ? FftTail2_8192::TAB * 8 : 0);   // + the second pass' twiddle table
     auto kern = stft_stereo_kernel<LR, PP>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
