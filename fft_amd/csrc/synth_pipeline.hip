@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "lds_fft.h"
+#include "lds_fft_tail2.h"
 #include "runtime.h"
 #include "synth_gen.h"
 
@@ -99,8 +100,12 @@ synth_pipeline_kernel(PipeArgs a) {
 #pragma unroll
         for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tl + TPF * u];
     }
+    // n = 16384 (8192 complex points, 512 threads): the transform's last radix-2 pass is folded into the Hermitian
+    // post-pass (lds_fft_tail2.h)
+    constexpr bool T2 = LOG2M == 13 && PP == 16;
     TwRegs<float, LOG2M, PP> tw;
-    tw.load(a.twM, tl);
+    FftTail2_8192 tw2;
+    if constexpr (T2) tw2.load(a.twM, tl, reinterpret_cast<float2*>(red_k + NW)); else tw.load(a.twM, tl);
 
     for (int64_t f = blockIdx.x; f < a.batch; f += gridDim.x) {
         sa_gen_params p = a.params[f];
@@ -181,7 +186,8 @@ synth_pipeline_kernel(PipeArgs a) {
             for (int i = 0; i < P; ++i) { v[i].x *= wl[i].x; v[i].y *= wl[i].y; }
         }
         __syncthreads();                                // every thread has its samples: the staging arrays may be overwritten
-        lds_fft_tw<float, LOG2M, PP>(v, buf, tl, tw);
+        if constexpr (T2) { tw2.run(v, buf, tl); __syncthreads(); }
+        else lds_fft_tw<float, LOG2M, PP>(v, buf, tl, tw);
         // ---- 4. Hermitian post-pass, magnitudes, peak ---------------------------------------------------
         asm volatile("" : "+v"(tq));
         tq &= TPF - 1;
@@ -197,6 +203,51 @@ synth_pipeline_kernel(PipeArgs a) {
                 const bool g = !(excl && (k == 0 || k == M)) && (m > best || (m == best && k < bk));
                 best = g ? m : best; bk = g ? k : bk;
             };
+            // (zq, zm) = (Z[q], Z[M - q]) -> bins q and M - q; w = w_n^q
+            auto pair = [&](float2 zq, float2 zm, float2 wq, int q, int voff_q, int soff_q, int voff_m, int soff_m) {
+                const float2 e = mk<float>(zq.x + zm.x, zq.y - zm.y);          // the 1/2 is in the window
+                const float2 d = mk<float>(zq.x - zm.x, zq.y + zm.y);
+                const float2 wo = cmul(mk<float>(d.y, -d.x), wq);
+                const float2 xa = cadd(e, wo), xb = csub(e, wo);
+                consider(mag_sqrt(xa.x * xa.x + xa.y * xa.y), q, voff_q, soff_q);
+                consider(mag_sqrt(xb.x * xb.x + xb.y * xb.y), M - q, voff_m, soff_m);
+            };
+            if constexpr (T2) {
+                // Legs of the final radix-2 butterflies: Z[j] = E[j] + O[j], Z[j + M/2] = E[j] - O[j] (j < M/2).  A thread
+                // takes butterflies j = tq + TPF u < M/4 and their mirrors M/2 - j: pair A is q = j with
+                // Z[M - j] = E[M/2 - j] - O[M/2 - j], pair B is q = M/2 - j with Z[M/2 + j] = E[j] - O[j] and the factor
+                // w_n^(M/2 - j) = -i conj(w_n^j).  Lane 0's j = 0 is its own mirror: (Z[0], Z[0]) and (Z[M/2], Z[M/2]).
+                constexpr int H = M / 2, PLANE = FftTail2_8192::PLANE;
+                const float2* pe = buf + lds_pad<S>(tq);
+                const int mlow = lds_pad<S>(TPF - tq);
+                float2 tj[H / 2 / TPF];
+#pragma unroll
+                for (int u = 0; u < H / 2 / TPF; ++u) tj[u] = a.twN[tq + TPF * u];
+#pragma unroll
+                for (int u = 0; u < H / 2 / TPF; ++u) {
+                    const int j = tq + TPF * u;
+                    const int moff = lds_pad_c<S>(H - TPF * (u + 1));
+                    const int m0 = lds_pad_c<S>((H - TPF * u) & (H - 1)) - moff;
+                    const int ml = (tq == 0 ? m0 : mlow) + moff;
+                    const float2 ej = pe[lds_pad_c<S>(TPF * u)], oj = pe[PLANE + lds_pad_c<S>(TPF * u)];
+                    const float2 em = buf[ml], om = buf[PLANE + ml];
+                    float2 za = cadd(ej, oj), zam = csub(em, om), zb = cadd(em, om), zbm = csub(ej, oj);
+                    if (u == 0) {                                   // j = 0: (S, D, S, D) -> (S, S), (D, D)
+                        const bool z0 = tq == 0;
+                        const float2 t = zam;
+                        zam.x = z0 ? zb.x : zam.x; zam.y = z0 ? zb.y : zam.y;
+                        zb.x = z0 ? t.x : zb.x;    zb.y = z0 ? t.y : zb.y;
+                    }
+                    pair(za, zam, tj[u], j, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
+                    pair(zb, zbm, mk<float>(-tj[u].y, -tj[u].x), H - j, (TPF - tq) * 4, (H - TPF * (u + 1)) * 4,
+                         tq * 4, (H + TPF * u) * 4);
+                }
+                if (tq == 0) {                                      // butterfly M/4 is its own mirror: bins M/4 and 3M/4
+                    const float2 e = buf[lds_pad_c<S>(H / 2)], o = buf[PLANE + lds_pad_c<S>(H / 2)];
+                    pair(cadd(e, o), csub(e, o), a.twN[H / 2], H / 2, 0, (H / 2) * 4, 0, (M - H / 2) * 4);
+                }
+                return;
+            }
             // additive padded addresses: Z[q] at pad(tq) + pad(TPF u), its mirror at pad(TPF - tq) + a constant for
             // every lane but tq = 0 (see rfft_generic.h)
             const float2* pq = buf + lds_pad<S>(tq);
@@ -212,12 +263,7 @@ synth_pipeline_kernel(PipeArgs a) {
                 const int moff = lds_pad_c<S>(M - TPF * (u + 1));
                 const int m0 = lds_pad_c<S>((M - TPF * u) & (M - 1)) - moff;
                 const float2 zq = pq[lds_pad_c<S>(TPF * u)], zm = buf[(tq == 0 ? m0 : mlow) + moff];
-                const float2 e = mk<float>(zq.x + zm.x, zq.y - zm.y);          // the 1/2 is in the window
-                const float2 d = mk<float>(zq.x - zm.x, zq.y + zm.y);
-                const float2 wo = cmul(mk<float>(d.y, -d.x), HOIST ? tn[u] : tl_[u]);
-                const float2 xa = cadd(e, wo), xb = csub(e, wo);
-                consider(mag_sqrt(xa.x * xa.x + xa.y * xa.y), q, tq * 4, TPF * u * 4);
-                consider(mag_sqrt(xb.x * xb.x + xb.y * xb.y), M - q, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
+                pair(zq, zm, HOIST ? tn[u] : tl_[u], q, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
             }
             if (tq == 0) {                                  // bin M/2: X = conj(Z[M/2])
                 const float2 z = buf[lds_pad_c<S>(M / 2)];
@@ -225,13 +271,21 @@ synth_pipeline_kernel(PipeArgs a) {
             }
         };
         if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});
-        constexpr int WRED = TPF < 64 ? TPF : 64;
+        if constexpr (TPF >= 64) {
+            // whole waves per frame: wave maximum, then the lowest bin among the lanes that hold it, on the DPP path.  A lane
+            // whose bins were all NaN still carries -1: it enters as 0 with no bin (rfft_generic.h)
+            const float wb = wave_max_f32(fmaxf(best, 0.0f));
+            bk = wave_min_u32(best == wb ? (unsigned)bk : 0x7fffffffu);
+            best = bk == 0x7fffffff ? -1.f : wb;
+        } else {
+            constexpr int WRED = TPF;
 #pragma unroll
-        for (int off = WRED / 2; off > 0; off >>= 1) {
-            const float om = __shfl_xor(best, off);
-            const int ok = __shfl_xor(bk, off);
-            const bool tk = (om > best) | ((om == best) & (ok < bk));
-            best = tk ? om : best; bk = tk ? ok : bk;
+            for (int off = WRED / 2; off > 0; off >>= 1) {
+                const float om = __shfl_xor(best, off);
+                const int ok = __shfl_xor(bk, off);
+                const bool tk = (om > best) | ((om == best) & (ok < bk));
+                best = tk ? om : best; bk = tk ? ok : bk;
+            }
         }
         if constexpr (TPF > 64) {
             if ((threadIdx.x & 63) == 0) { red_m[threadIdx.x >> 6] = best; red_k[threadIdx.x >> 6] = bk; }
@@ -292,7 +346,8 @@ template <int LOG2M, int U, int PP>
 static int launch_pipe_pp(const PipeArgs& a, hipStream_t st) {
     constexpr int NBASE = (2 << LOG2M) / U;
     constexpr int NW = (FftPlan<LOG2M, PP>::TPF + 63) / 64;
-    constexpr int lds = lds_fft_elems<float, LOG2M>() * 8 + NW * 8 + 32;                  // staging arrays alias the transform buffer
+    constexpr int lds = lds_fft_elems<float, LOG2M>() * 8 + NW * 8 + 32 +                // staging arrays alias the transform buffer
+                        (LOG2M == 13 && PP == 16 ? FftTail2_8192::TAB * 8 : 0);          // + the second pass' twiddle table
     (void)NBASE;
     auto kern = synth_pipeline_kernel<LOG2M, U, PP, GEN_LIGHT>;
     auto kern_heavy = synth_pipeline_kernel<LOG2M, U, PP, GEN_HEAVY>;
