@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "lds_fft.h"
+#include "lds_fft_tail2.h"
 
 namespace sa {
 
@@ -65,10 +66,16 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
     constexpr bool HOIST = sizeof(T) == 4;
     constexpr int R0 = PL::radix(0);
     constexpr int NIT = (M / 2) / TPF;
+    // fp32 n = 16384 (8192 complex points, 512 threads): the transform's last radix-2 pass is folded into the Hermitian
+    // post-pass (lds_fft_tail2.h); that path needs the factors w_N^q of the first quarter only
+    constexpr bool T2 = sizeof(T) == 4 && LOG2M == 13 && P == 16 && FPW == 1;
+    constexpr int NTN = T2 ? NIT / 2 : NIT;
     TwRegs<T, LOG2M, P> tw;
-    tw.load(a.twM, tl);
+    FftTail2_8192 tw2;
+    if constexpr (T2) tw2.load(reinterpret_cast<const float2*>(a.twM), tl, reinterpret_cast<float2*>(red_bin + NWAVES));
+    else tw.load(a.twM, tl);
     C w[HOIST ? P : 1];
-    C tn[NIT];
+    C tn[NTN];
     if constexpr (HOIST) {
         if (a.win) {
 #pragma unroll
@@ -84,7 +91,7 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
 #pragma unroll
         for (int i = 0; i < P; ++i) { w[i].x *= (T)0.5; w[i].y *= (T)0.5; }
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tl + TPF * u];
+        for (int u = 0; u < NTN; ++u) tn[u] = a.twN[tl + TPF * u];
     }
 
     for (int64_t base = (int64_t)blockIdx.x * FPW; base < a.batch; base += (int64_t)gridDim.x * FPW) {
@@ -129,14 +136,15 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                 for (int i = 0; i < P; ++i) { v[i].x *= wl[i].x; v[i].y *= wl[i].y; }
             }
         }
-        lds_fft_tw<T, LOG2M, P, false>(v, buf, tl, tw);
+        if constexpr (T2) tw2.run(reinterpret_cast<float2*>(v), reinterpret_cast<float2*>(buf), tl);
+        else lds_fft_tw<T, LOG2M, P, false>(v, buf, tl, tw);
 
         // ---------------- Hermitian post-pass: Z -> X[0..M], |X|, peak ----------------------
         // pair q < M/2 gives bins q and M-q; thread 0 adds the self-paired bin M/2.  Without hoisting the
         // w_N^q factors are requested before the barrier that publishes Z.
         if constexpr (!HOIST) {
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) tn[u] = a.twN[tq + TPF * u];
+            for (int u = 0; u < NTN; ++u) tn[u] = a.twN[tq + TPF * u];
         }
         __syncthreads();
         T best = (T)-1;
@@ -157,19 +165,14 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
             const C* pq = buf + lds_pad<S>(tq);
             const int mlow = lds_pad<S>(TPF - tq);
             constexpr T HALF = HOIST ? (T)1 : (T)0.5;        // fp32: already in the window
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int q = tq + TPF * u;
-                const int moff = lds_pad_c<S>(M - TPF * (u + 1));
-                const int m0 = lds_pad_c<S>((M - TPF * u) & (M - 1)) - moff;       // what tq = 0 needs in place of mlow
-                const C zq = pq[lds_pad_c<S>(TPF * u)];
-                const C zm = buf[(tq == 0 ? m0 : mlow) + moff];
+            // (zq, zm) = (Z[q], Z[M - q]) and wq = w_N^q give bins q and M - q; DC0: q may be 0 (lane tq == 0)
+            auto pair = [&](C zq, C zm, C wq, int q, auto DC0) {
                 // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
                 const C e0 = mk<T>(HALF * (zq.x + zm.x), HALF * (zq.y - zm.y));
                 const C d = mk<T>(HALF * (zq.x - zm.x), HALF * (zq.y + zm.y));
-                C wo = cmul(mk<T>(d.y, -d.x), tn[u]);
+                C wo = cmul(mk<T>(d.y, -d.x), wq);
                 C e = e0;
-                if (u == 0) {
+                if constexpr (decltype(DC0)::value) {
                     // q = 0: X[0] = Re Z0 + Im Z0 and X[M] = Re Z0 - Im Z0 exactly.  Finite data give the same bits either
                     // way; with overflowed samples (the reference's Hiperbólica reaches sinh = inf, main.py:586) the general
                     // formula would turn DC into inf - inf = NaN where the reference's plain sum reads +-inf.
@@ -188,6 +191,50 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                 best = ga ? ma : best; best_k = ga ? ka : best_k;
                 const bool gb = !(excl && kb == M) && peak_better(mb, kb, best, best_k);
                 best = gb ? mb : best; best_k = gb ? kb : best_k;
+            };
+            if constexpr (T2) {
+                // Legs of the final radix-2 butterflies: Z[j] = E[j] + O[j], Z[j + M/2] = E[j] - O[j] (j < M/2).  A thread
+                // takes butterflies j = tq + TPF u < M/4 and their mirrors M/2 - j: pair A is q = j with
+                // Z[M - j] = E[M/2 - j] - O[M/2 - j], pair B is q = M/2 - j with Z[M/2 + j] = E[j] - O[j] and the factor
+                // w_N^(M/2 - j) = -i conj(w_N^j).  Lane 0's j = 0 is its own mirror: pairs (Z[0], Z[0]) and (Z[M/2], Z[M/2]);
+                // the latter yields bin M/2 (twice, same value), which the general path leaves to thread 0.
+                constexpr int H = M / 2, PLANE = FftTail2_8192::PLANE;
+                const C* pe = buf + lds_pad<S>(tq);
+#pragma unroll
+                for (int u = 0; u < NTN; ++u) {
+                    const int j = tq + TPF * u;
+                    const int moff = lds_pad_c<S>(H - TPF * (u + 1));
+                    const int m0 = lds_pad_c<S>((H - TPF * u) & (H - 1)) - moff;
+                    const int ml = (tq == 0 ? m0 : mlow) + moff;
+                    const C ej = pe[lds_pad_c<S>(TPF * u)], oj = pe[PLANE + lds_pad_c<S>(TPF * u)];
+                    const C em = buf[ml], om = buf[PLANE + ml];
+                    C za = cadd(ej, oj), zam = csub(em, om), zb = cadd(em, om), zbm = csub(ej, oj);
+                    if (u == 0) {                                   // j = 0: (S, D, S, D) -> (S, S), (D, D)
+                        const bool z0 = tq == 0;
+                        const C t = zam;
+                        zam.x = z0 ? zb.x : zam.x; zam.y = z0 ? zb.y : zam.y;
+                        zb.x = z0 ? t.x : zb.x;    zb.y = z0 ? t.y : zb.y;
+                        pair(za, zam, tn[u], j, std::true_type{});
+                    } else {
+                        pair(za, zam, tn[u], j, std::false_type{});
+                    }
+                    pair(zb, zbm, mk<T>(-tn[u].y, -tn[u].x), H - j, std::false_type{});
+                }
+                if (tq == 0) {                                      // butterfly M/4 is its own mirror: bins M/4 and 3M/4
+                    const C e = buf[lds_pad_c<S>(H / 2)], o = buf[PLANE + lds_pad_c<S>(H / 2)];
+                    pair(cadd(e, o), csub(e, o), a.twN[H / 2], H / 2, std::false_type{});
+                }
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int q = tq + TPF * u;
+                const int moff = lds_pad_c<S>(M - TPF * (u + 1));
+                const int m0 = lds_pad_c<S>((M - TPF * u) & (M - 1)) - moff;       // what tq = 0 needs in place of mlow
+                const C zq = pq[lds_pad_c<S>(TPF * u)];
+                const C zm = buf[(tq == 0 ? m0 : mlow) + moff];
+                if (u == 0) pair(zq, zm, tn[u < NTN ? u : 0], q, std::true_type{});
+                else pair(zq, zm, tn[u < NTN ? u : 0], q, std::false_type{});
             }
             if (tq == 0) {                           // bin M/2: X = conj(Z[M/2])
                 const C z = buf[lds_pad_c<S>(M / 2)];
