@@ -237,6 +237,54 @@ def test_kats_impulse_dc_nyquist_ties():
     np.testing.assert_allclose(mag[3], 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("n", [8192, 16384, 32768])
+def test_kats_and_flags_on_the_largest_single_pass_sizes(n):
+    """n = 16384 runs the tail-folded 8192-point transform (lds_fft_tail2.h): lane 0 pairs (Z[0], Z[0]) and (Z[M/2], Z[M/2]),
+    butterfly M/4 is its own mirror (bins M/4 and 3M/4), pair B uses -i conj(w).  Known answers on exactly those bins,
+    ties, and the flags, with the neighbouring sizes (general plans) as controls."""
+    import fft_amd
+    t = np.arange(n)
+    x = np.zeros((8, n), dtype=np.float32)
+    x[0, 0] = 1.0                                            # impulse: flat spectrum of ones, tie -> bin 0
+    x[1, :] = 1.0                                            # DC
+    x[2, ::2] = 1.0; x[2, 1::2] = -1.0                       # Nyquist
+    x[3] = np.cos(2 * np.pi * (n // 4) * t / n)              # bin n/4 (= M/2 of the packed transform)
+    x[4] = np.cos(2 * np.pi * (n // 8) * t / n)              # bin n/8 (= M/4: the self-mirrored butterfly)
+    x[5] = np.cos(2 * np.pi * (3 * n // 8) * t / n)          # bin 3n/8 (= 3M/4)
+    x[6] = np.cos(2 * np.pi * 1 * t / n)                     # bin 1, next to DC
+    x[7] = np.cos(2 * np.pi * (n // 2 - 1) * t / n)          # bin n/2 - 1, next to Nyquist
+    mag, pb, pm = fft_amd.rfft_peak(x, "none")
+    np.testing.assert_allclose(mag[0], 1.0, atol=2e-6)
+    assert pb[0] == np.argmax(mag[0])
+    assert pb[1] == 0 and pm[1] == n and pb[2] == n // 2 and pm[2] == n
+    for row, k in ((3, n // 4), (4, n // 8), (5, 3 * n // 8), (6, 1), (7, n // 2 - 1)):
+        assert pb[row] == k and pm[row] == pytest.approx(n / 2, rel=1e-6)
+        others = np.delete(mag[row], k)
+        assert others.max() < 1e-3 * n / 2
+    np.testing.assert_array_equal(pb, np.argmax(mag, axis=1))
+    # all-zero frames: every bin ties
+    z = np.zeros((3, n), dtype=np.float32)
+    _, pbz, _ = fft_amd.rfft_peak(z, "hann")
+    assert (pbz == 0).all()
+    _, pbz, _ = fft_amd.rfft_peak(z, "hann", exclude_dc_nyq=True)
+    assert (pbz == 1).all()
+    # flags against the linear spectrum of the same kernel
+    rng = np.random.default_rng(n)
+    y = (2.0 + np.sin(2 * np.pi * 0.2 * t) + 0.3 * rng.standard_normal((5, n))).astype(np.float32)
+    m0, p0, q0 = fft_amd.rfft_peak(y, "hamming")
+    assert (p0 == 0).all()                                   # the offset dominates
+    m1, p1, q1 = fft_amd.rfft_peak(y, "hamming", exclude_dc_nyq=True)
+    np.testing.assert_array_equal(m1, m0)
+    np.testing.assert_array_equal(p1, 1 + np.argmax(m0[:, 1:n // 2], axis=1))
+    none_, p2, q2 = fft_amd.rfft_peak(y, "hamming", write_mag=False)
+    assert none_ is None
+    np.testing.assert_array_equal(p2, p0); np.testing.assert_array_equal(q2, q0)
+    mdb, p3, _ = fft_amd.rfft_peak(y, "hamming", db=True)
+    np.testing.assert_array_equal(p3, p0)
+    live = m0 > 0
+    assert np.abs(mdb[live] - 20 * np.log10(m0[live].astype(np.float64))).max() < 2e-4
+
+
 def test_bad_arguments_raise_valueerror():
     import fft_amd
     with pytest.raises(ValueError):
