@@ -9,7 +9,10 @@
 // The twiddles after the third pass have two distinct bases only, w_32^0 and w_32^1, chosen by the parity of the
 // butterfly index.  The butterflies are dealt so that this parity is the thread's bit 8: whole waves either skip the
 // twiddles or multiply by the fifteen CONSTANTS w_32^k (no power tree, on average 30 instructions instead of 116).
-// The legs are written as two planes (parity = plane), lane-contiguous in q.
+// The legs are written as two planes (parity = plane), lane-contiguous in q.  The second pass' fifteen powers per thread
+// come from a 3.8 KiB table in LDS (the caller provides the space after its own LDS data).
+// Users: stft.hip (nfft 8192), synth_pipeline.hip (n = 16384), rfft_generic.h (fp32 n = 16384); each folds the last
+// butterflies into its own epilogue, taking butterflies j < 2048 together with their mirrors 4096 - j.
 #pragma once
 #include "lds_fft.h"
 
