@@ -13,7 +13,10 @@
 // come from a 3.8 KiB table in LDS (the caller provides the space after its own LDS data).
 // Users: stft.hip (nfft 8192), synth_pipeline.hip (n = 16384), rfft_generic.h (fp32 n = 16384); each folds the last
 // butterflies into its own epilogue, taking butterflies j < 2048 together with their mirrors 4096 - j.
+// FftTail4_16384 below is the radix-4 form for fp32 n = 32768 (rfft_generic.h).
 #pragma once
+#include <utility>
+
 #include "lds_fft.h"
 
 namespace sa {
@@ -100,6 +103,115 @@ struct FftTail2_8192 {
                 __syncthreads();
 #pragma unroll
                 for (int k = 0; k < 16; ++k) wr[lds_pad_c<S>(256 * k)] = v[k];
+            }
+        }
+    }
+};
+
+// 16384 = 16 * 16 * 16 * 4 with 1024 threads x 16 points (fp32 n = 32768): the same idea with a radix-4 tail.  The three
+// radix-16 passes leave the four legs l_n[q] of every final butterfly q < 4096 in LDS as four planes,
+//     Z[q + 4096 k] = sum_n l_n[q] (-i)^(n k),   k = 0..3,
+// and the caller's epilogue forms them.  The third pass' twiddles have the bases w_64^p, p = butterfly index mod 4; the
+// butterflies are dealt so that p is bits 8-9 of the thread index (wave-uniform): constants w_64^(p k), none for p = 0.
+struct FftTail4_16384 {
+    static constexpr int LR = 14, R = 16384, TPF = 1024, P = 16, S = 5;
+    static constexpr int PLANE = lds_pad_c<S>(4096) + 2;           // leg n of butterfly q: buf[n * PLANE + lds_pad<S>(q)]
+    static_assert(4 * PLANE <= lds_fft_elems<float, LR>(), "leg planes fit the transform's buffer");
+    static constexpr int TAB = 15 * 64;  // float2 elements: w_1024^(m k), m = tl % 64, [k][m]
+    float2 w0;                           // w_16384^tl
+    const float2* tab;
+    __device__ __forceinline__ void load(const float2* __restrict__ twR, int tl, float2* lds_tab) {
+        w0 = twR[tl & (TPF - 1)];
+        if (tl < TAB) lds_tab[tl] = twR[(16 * (tl & 63) * ((tl >> 6) + 1)) & (R - 1)];
+        tab = lds_tab + (tl & 63);
+    }
+    // one pad element per 64: the third pass' gather has its lanes 65 elements apart (a half-wave covers the banks once)
+    static __device__ __forceinline__ int pad64(int a) { return a + (a >> 6); }
+    static constexpr int pad64c(int a) { return a + (a >> 6); }
+    // cos(2 pi e / 64), e = 0..63, from the first quadrant
+    static constexpr float cos64(int e) {
+        constexpr float q[17] = {1.f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f,
+                                 0.92387953251128675613f, 0.88192126434835502971f, 0.83146961230254523708f,
+                                 0.77301045336273696081f, 0.70710678118654752440f, 0.63439328416364549822f,
+                                 0.55557023301960222474f, 0.47139673682599764856f, 0.38268343236508977173f,
+                                 0.29028467725446236764f, 0.19509032201612826785f, 0.09801714032956060199f, 0.f};
+        e &= 63;
+        return e <= 16 ? q[e] : e <= 32 ? -q[32 - e] : e <= 48 ? -q[e - 32] : q[64 - e];
+    }
+
+    template <int E>
+    static __device__ __forceinline__ float2 mul_w64(float2 a) {             // a * w_64^E, E a compile-time constant
+        constexpr int e = E & 63;
+        if constexpr (e == 0) return a;
+        else if constexpr (e == 16) return mul_mi(a);
+        else if constexpr (e == 32) return mk<float>(-a.x, -a.y);
+        else if constexpr (e == 48) return mk<float>(-a.y, a.x);
+        else {
+            constexpr float c = cos64(e), sn = cos64(e - 16);                // sin x = cos(x - pi/2)
+            return cmul(a, mk<float>(c, -sn));
+        }
+    }
+    template <int PAR, int... K>
+    static __device__ __forceinline__ void twiddle_consts_impl(float2* v, std::integer_sequence<int, K...>) {
+        ((v[K + 1] = mul_w64<PAR * (K + 1)>(v[K + 1])), ...);
+    }
+    template <int PAR>
+    static __device__ __forceinline__ void twiddle_consts(float2* v) {       // v[k] *= w_64^(PAR k), k = 1..15
+        twiddle_consts_impl<PAR>(v, std::make_integer_sequence<int, 15>{});
+    }
+
+    __device__ __forceinline__ void run(float2* v, float2* buf, int tl) const {
+        asm volatile("" : "+v"(tl));
+        tl &= TPF - 1;
+        {   // pass 0: radix 16 over n1 (stride 1024), twiddle w_16384^(tl k), element a = tl + 1024 k
+            float2* wr = buf + lds_pad_m<S, 1>(tl);
+            bfly16<float>(v);
+            apply_twiddle_powers<float, 16>(v, FftTail2_8192::opaque(w0));
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wr[lds_pad_mc<S, 1>(1024 * k)] = v[k];
+        }
+        {   // pass 1: butterfly tl gathers (tl / 64) 1024 + tl % 64 + 64 n, twiddle w_1024^((tl % 64) k) from the table
+            const float2* rd = buf + lds_pad_m<S, 1>((tl >> 6) * 1024 + (tl & 63));
+            float2* wr = buf + pad64(tl);
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < 16; ++n) v[n] = rd[lds_pad_mc<S, 1>(64 * n)];
+            bfly16<float>(v);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tab[64 * (k - 1)]);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wr[pad64c(1024 * k)] = v[k];
+        }
+        {   // pass 2: butterfly id = 4 (tl % 256) + (tl / 256) gathers (id / 4) 64 + id % 4 + 4 n
+            const int par = __builtin_amdgcn_readfirstlane(tl >> 8), lo = tl & 255;
+            const float2* rd = buf + lo * 65 + par;
+            float2* wr = buf + par * PLANE + lds_pad<S>(lo);
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < 16; ++n) v[n] = rd[4 * n];
+            bfly16<float>(v);
+            // element id + 1024 k is leg id % 4 of final butterfly q = id / 4 + 256 k = lo + 256 k.  Barrier and stores in
+            // every arm, in a different order each, so that the compiler does not re-join the arms (FftTail2_8192::run)
+            if (par == 0) {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wr[lds_pad_c<S>(256 * k)] = v[k];
+            } else if (par == 1) {
+                twiddle_consts<1>(v);
+                __syncthreads();
+#pragma unroll
+                for (int k = 15; k >= 0; --k) wr[lds_pad_c<S>(256 * k)] = v[k];
+            } else if (par == 2) {
+                twiddle_consts<2>(v);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wr[lds_pad_c<S>(256 * (k ^ 8))] = v[k ^ 8];
+            } else {
+                twiddle_consts<3>(v);
+                __syncthreads();
+#pragma unroll
+                for (int k = 15; k >= 0; --k) wr[lds_pad_c<S>(256 * (k ^ 8))] = v[k ^ 8];
             }
         }
     }

@@ -21,7 +21,8 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     constexpr int NTHREADS = TPF * FPW;
     constexpr int NWAVES = (NTHREADS + 63) / 64;
     constexpr size_t lds = (size_t)FPW * LDS_PER_FRAME * sizeof(cplx<T>) + NWAVES * (sizeof(T) + sizeof(int)) + 16 +
-                           (sizeof(T) == 4 && LOG2M == 13 && P == 16 && FPW == 1 ? FftTail2_8192::TAB * 8 : 0);   // twiddle table (rfft_generic.h: T2)
+                           (sizeof(T) == 4 && LOG2M == 13 && P == 16 && FPW == 1 ? FftTail2_8192::TAB * 8 : 0) +   // twiddle tables (rfft_generic.h: T2, T4)
+                           (sizeof(T) == 4 && LOG2M == 14 && P == 16 && FPW == 1 ? FftTail4_16384::TAB * 8 : 0);
     static_assert(lds <= 160 * 1024, "frame does not fit LDS");
     auto kern = rfft_mag_peak_generic<T, LOG2M, P, FPW>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)

@@ -69,10 +69,14 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
     // fp32 n = 16384 (8192 complex points, 512 threads): the transform's last radix-2 pass is folded into the Hermitian
     // post-pass (lds_fft_tail2.h); that path needs the factors w_N^q of the first quarter only
     constexpr bool T2 = sizeof(T) == 4 && LOG2M == 13 && P == 16 && FPW == 1;
-    constexpr int NTN = T2 ? NIT / 2 : NIT;
+    // fp32 n = 32768 (16384 complex points, 1024 threads): the same with a radix-4 tail; factors of the first eighth
+    constexpr bool T4 = sizeof(T) == 4 && LOG2M == 14 && P == 16 && FPW == 1;
+    constexpr int NTN = T2 ? NIT / 2 : T4 ? NIT / 4 : NIT;
     TwRegs<T, LOG2M, P> tw;
     FftTail2_8192 tw2;
+    FftTail4_16384 tw4;
     if constexpr (T2) tw2.load(reinterpret_cast<const float2*>(a.twM), tl, reinterpret_cast<float2*>(red_bin + NWAVES));
+    else if constexpr (T4) tw4.load(reinterpret_cast<const float2*>(a.twM), tl, reinterpret_cast<float2*>(red_bin + NWAVES));
     else tw.load(a.twM, tl);
     C w[HOIST ? P : 1];
     C tn[NTN];
@@ -137,6 +141,7 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
             }
         }
         if constexpr (T2) tw2.run(reinterpret_cast<float2*>(v), reinterpret_cast<float2*>(buf), tl);
+        else if constexpr (T4) tw4.run(reinterpret_cast<float2*>(v), reinterpret_cast<float2*>(buf), tl);
         else lds_fft_tw<T, LOG2M, P, false>(v, buf, tl, tw);
 
         // ---------------- Hermitian post-pass: Z -> X[0..M], |X|, peak ----------------------
@@ -224,6 +229,51 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                     const C e = buf[lds_pad_c<S>(H / 2)], o = buf[PLANE + lds_pad_c<S>(H / 2)];
                     pair(cadd(e, o), csub(e, o), a.twN[H / 2], H / 2, std::false_type{});
                 }
+                return;
+            }
+            if constexpr (T4) {
+                // Legs l_n[j] of the final radix-4 butterflies j < M/4: Z[j + (M/4) k] = sum_n l_n[j] (-i)^(n k).  A thread takes
+                // butterflies j = tq + TPF u < M/8 and their mirrors M/4 - j; the eight transforms A[k] = Z[j + (M/4) k],
+                // B[k] = Z[M/4 - j + (M/4) k] close under the Hermitian pairing:
+                //   q = j: (A0, B3), w;   q = j + M/4: (A1, B2), w_8 w;   q = M/2 - j: (B1, A2), -i conj w;   q = M/4 - j: (B0, A3), w_8 conj w.
+                // Lane 0's j = 0 is its own mirror with B[k] = A[(k + 1) % 4]; its q = M/2 pair is (Z[M/2], Z[M/2]) and yields bin
+                // M/2, its q = M/4 pair comes out twice with the same values.
+                constexpr int Q = M / 4, PLANE = FftTail4_16384::PLANE;
+                constexpr T h = (T)0.70710678118654752440;
+                const C* pe = buf + lds_pad<S>(tq);
+                auto quad = [&](int off, C* z) {                       // the four outputs of the butterfly whose legs sit at off
+                    z[0] = buf[off]; z[1] = buf[PLANE + off]; z[2] = buf[2 * PLANE + off]; z[3] = buf[3 * PLANE + off];
+                    bfly4(z[0], z[1], z[2], z[3]);
+                };
+#pragma unroll
+                for (int u = 0; u < NTN; ++u) {
+                    const int j = tq + TPF * u;
+                    const int moff = lds_pad_c<S>(Q - TPF * (u + 1));
+                    const int m0 = lds_pad_c<S>((Q - TPF * u) & (Q - 1)) - moff;
+                    C A[4], B[4];
+                    quad(lds_pad<S>(tq) + lds_pad_c<S>(TPF * u), A);
+                    quad((tq == 0 ? m0 : mlow) + moff, B);
+                    if (u == 0) {
+                        const bool z0 = tq == 0;                       // B[k] = A[(k + 1) % 4]
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { B[k].x = z0 ? A[(k + 1) & 3].x : B[k].x; B[k].y = z0 ? A[(k + 1) & 3].y : B[k].y; }
+                    }
+                    const C w = tn[u], wc = mk<T>(w.x, -w.y);
+                    const C w8w = mk<T>(h * (w.x + w.y), h * (w.y - w.x));           // (h - i h) w
+                    const C w8wc = mk<T>(h * (wc.x + wc.y), h * (wc.y - wc.x));      // (h - i h) conj w
+                    if (u == 0) pair(A[0], B[3], w, j, std::true_type{});
+                    else pair(A[0], B[3], w, j, std::false_type{});
+                    pair(A[1], B[2], w8w, j + Q, std::false_type{});
+                    pair(B[1], A[2], mk<T>(-w.y, -w.x), 2 * Q - j, std::false_type{});
+                    pair(B[0], A[3], w8wc, Q - j, std::false_type{});
+                }
+                if (tq == 0) {                                         // butterfly M/8 is its own mirror: bins M/8, 3M/8, 5M/8, 7M/8
+                    C A[4];
+                    quad(lds_pad_c<S>(Q / 2), A);
+                    pair(A[0], A[3], a.twN[Q / 2], Q / 2, std::false_type{});
+                    pair(A[1], A[2], a.twN[Q / 2 + Q], Q / 2 + Q, std::false_type{});
+                }
+                (void)pe;
                 return;
             }
 #pragma unroll
