@@ -56,7 +56,8 @@ def test_stft_other_channel_counts(ch):
     check(synth_pcm(30000, ch, ch), 2048, 512, "none")
 
 
-@pytest.mark.parametrize("ch,nfft,hop", [(1, 1024, 255), (1, 4096, 1023), (1, 64, 1), (3, 2048, 511), (2, 16384, 4097)])
+@pytest.mark.parametrize("ch,nfft,hop", [(1, 1024, 255), (1, 4096, 1023), (1, 64, 1), (3, 2048, 511), (2, 16384, 4097), (1, 32768, 8191),
+                                          (1, 16384, 4096)])
 def test_stft_odd_hop_deinterleaved_paths(ch, nfft, hop):
     """Odd hops start every other frame on an odd sample; the de-interleaved (mono / 3-channel / nfft > 8192) paths
     then load the frames element-wise (rfft_generic.h, RfftArgs::unaligned).  4096-point frames at an odd hop also

@@ -55,7 +55,7 @@ def make_frames(rng, batch, n, dtype):
 
 def case_rfft(rng):
     dtype = np.float32 if rng.random() < 0.6 else np.float64
-    n = 1 << int(rng.integers(4, 15))
+    n = 1 << int(rng.integers(4, 16))                    # to 32768: fp32's largest single-pass size, fp64's first four-step one
     batch = int(rng.integers(1, max(2, min(3000, (1 << 22) // n))))
     win = WINDOWS[rng.integers(0, len(WINDOWS))]
     wp = float(rng.uniform(n / 20, n / 3)) if win == "gaussian" else 0.0
