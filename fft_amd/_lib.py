@@ -99,10 +99,12 @@ class DistInfo(C.Structure):
 class DistStats(C.Structure):
     """struct sa_dist_stats (include/specengine.h)."""
     _fields_ = [("n", _i64), ("bytes_per_peer", _i64), ("n_ranks", _i32), ("n_devices", _i32), ("exchange_mode", _i32),
-                ("n_chunks", _i32), ("exchanges", _i32), ("reserved", _i32), ("total_ms", _dbl), ("device_ms", _dbl),
+                ("n_chunks", _i32), ("exchanges", _i32), ("pairs_timed", _i32), ("total_ms", _dbl), ("device_ms", _dbl),
                 ("pass1_ms", _dbl), ("phase2_ms", _dbl), ("exchange_ms", _dbl), ("link_gbps_min", _dbl),
                 ("link_gbps_mean", _dbl), ("link_gbps_max", _dbl), ("aggregate_gbps", _dbl),
-                ("link_gbps", (_dbl * DIST_MAX_RANKS) * DIST_MAX_RANKS)]
+                ("link_gbps", (_dbl * DIST_MAX_RANKS) * DIST_MAX_RANKS),
+                ("rank_exchange_ms", _dbl * DIST_MAX_RANKS), ("rank_egress_gbps", _dbl * DIST_MAX_RANKS),
+                ("chunk_ms", _dbl * DIST_MAX_RANKS)]
 
 
 class GenParams(C.Structure):

@@ -389,12 +389,15 @@ done:
 }
 
 int sa_dist_plan_destroy(sa_dist_plan* plan) {
-    sa::dist_free(plan);
+    using namespace sa;
+    SA_ENTER();                                              // a concurrent sa_shutdown waits for us
+    dist_free(plan);
     return SA_OK;
 }
 
 int sa_dist_plan_info(const sa_dist_plan* p, int32_t rank, sa_dist_info* info) {
     using namespace sa;
+    SA_ENTER();
     if (!p || !info || rank < 0 || rank >= p->P) { set_error("sa_dist_plan_info: bad arguments"); return SA_EINVAL; }
     const sa_dist_rank& k = p->r[rank];
     memset(info, 0, sizeof(*info));
@@ -408,6 +411,7 @@ int sa_dist_plan_info(const sa_dist_plan* p, int32_t rank, sa_dist_info* info) {
 
 int sa_dist_fill(sa_dist_plan* p, int32_t kind, int64_t param, uint64_t seed) {
     using namespace sa;
+    SA_ENTER();
     if (!p) { set_error("sa_dist_fill: plan is NULL"); return SA_EINVAL; }
     if (kind < SA_DIST_KAT_IMPULSE || kind > SA_DIST_KAT_NOISE || ((kind != SA_DIST_KAT_NOISE) && (param < 0 || param >= p->n))) {
         set_error("sa_dist_fill: kind %d / index %lld out of range", kind, (long long)param);
@@ -427,6 +431,7 @@ int sa_dist_fill(sa_dist_plan* p, int32_t kind, int64_t param, uint64_t seed) {
 
 int sa_dist_check(sa_dist_plan* p, int32_t kind, int64_t param, double* max_abs_err) {
     using namespace sa;
+    SA_ENTER();
     if (!p || !max_abs_err) { set_error("sa_dist_check: NULL argument"); return SA_EINVAL; }
     if ((kind != SA_DIST_KAT_IMPULSE && kind != SA_DIST_KAT_TONE) || param < 0 || param >= p->n) {
         set_error("sa_dist_check: only the impulse and tone inputs have closed-form spectra");
@@ -459,6 +464,8 @@ int sa_dist_check(sa_dist_plan* p, int32_t kind, int64_t param, double* max_abs_
 
 int sa_dist_execute(sa_dist_plan* p, sa_dist_stats* stats) {
     using namespace sa;
+    // the guard keeps sa_shutdown from freeing the cached twiddle tables (get_cached_table) under the kernels queued below
+    SA_ENTER();
     if (!p) { set_error("sa_dist_execute: plan is NULL"); return SA_EINVAL; }
     const int P = p->P, J = p->J;
     const int64_t Sp = p->Sp, K1L = p->K1L, CH = p->CH, S = p->S;
@@ -508,7 +515,7 @@ int sa_dist_execute(sa_dist_plan* p, sa_dist_stats* stats) {
                 if (j == 0) {
                     SA_HIPD(hipSetDevice(k.dev));
                     SA_HIPD(hipStreamWaitEvent(k.copy[0], k.e_p1e, 0));
-                    for (int q = 0; q < P; ++q) SA_HIPD(hipEventRecord(k.e_cs[q], k.copy[0]));
+                    SA_HIPD(hipEventRecord(k.e_cs[0], k.copy[0]));   // ONE window per rank: RCCL does not time pairs apart
                 }
             }
             SA_NCCLD(nc->GroupStart());
@@ -531,10 +538,9 @@ int sa_dist_execute(sa_dist_plan* p, sa_dist_stats* stats) {
             for (int i = 0; i < P; ++i) {
                 sa_dist_rank& k = p->r[i];
                 SA_HIPD(hipSetDevice(k.dev));
-                for (int q = 0; q < P; ++q) {
-                    SA_HIPD(hipEventRecord(k.e_chunk[q][j], k.copy[0]));
-                    if (j == J - 1) SA_HIPD(hipEventRecord(k.e_ce[q], k.copy[0]));
-                }
+                // chunk j has arrived at THIS rank (its receives precede the event on its stream): slot [0][j] only
+                SA_HIPD(hipEventRecord(k.e_chunk[0][j], k.copy[0]));
+                if (j == J - 1) SA_HIPD(hipEventRecord(k.e_ce[0], k.copy[0]));
             }
         }
     } else if (p->mode != SA_DIST_XCHG_FUSED) {
@@ -568,8 +574,12 @@ int sa_dist_execute(sa_dist_plan* p, sa_dist_stats* stats) {
         for (int q = 0; q < P; ++q) {
             sa_dist_rank& k = p->r[q];
             SA_HIPD(hipSetDevice(k.dev));
-            for (int s = 0; s < P; ++s)
-                SA_HIPD(hipStreamWaitEvent(k.compute, p->mode == SA_DIST_XCHG_FUSED ? p->r[s].e_p1e : p->r[s].e_chunk[q][j], 0));
+            if (p->mode == SA_DIST_XCHG_RCCL) {
+                SA_HIPD(hipStreamWaitEvent(k.compute, k.e_chunk[0][j], 0));      // the owner's own stream has passed group j
+            } else {
+                for (int s = 0; s < P; ++s)
+                    SA_HIPD(hipStreamWaitEvent(k.compute, p->mode == SA_DIST_XCHG_FUSED ? p->r[s].e_p1e : p->r[s].e_chunk[q][j], 0));
+            }
             if (j == 0) SA_HIPD(hipEventRecord(k.e_p2s, k.compute));
             SA_TRYD(dist_phase2(k.recv + 2 * ((int64_t)j * CH * Sp), k.work, k.out + 2 * ((int64_t)j * CH * S), S, CH, Sp, blk, p->nt, k.compute));
             if (j == J - 1) SA_HIPD(hipEventRecord(k.e_p2e, k.compute));
@@ -623,8 +633,35 @@ done:
         if (hipEventElapsedTime(&ms, k.e_p1s, k.e_p1e) == hipSuccess && ms > stats->pass1_ms) stats->pass1_ms = ms;
         if (hipEventElapsedTime(&ms, k.e_p2s, k.e_p2e) == hipSuccess && ms > stats->phase2_ms) stats->phase2_ms = ms;
         if (hipEventElapsedTime(&ms, k.e_start, k.e_end) == hipSuccess && ms > stats->device_ms) stats->device_ms = ms;
+        if (p->mode == SA_DIST_XCHG_RCCL) {
+            // one window per rank (first group start -> last group end) and the time inside each chunk's group; the pairs
+            // of a rank are inside one RCCL kernel and cannot be timed apart: report the egress, spread evenly per link
+            double win = 0;
+            if (hipEventElapsedTime(&ms, k.e_cs[0], k.e_ce[0]) == hipSuccess) win = ms;
+            stats->rank_exchange_ms[i] = win;
+            if (win > xmax) xmax = win;
+            for (int j = 0; j < J && j < SA_DIST_MAX_RANKS; ++j)
+                if (hipEventElapsedTime(&ms, j ? k.e_chunk[0][j - 1] : k.e_cs[0], k.e_chunk[0][j]) == hipSuccess && ms > stats->chunk_ms[j])
+                    stats->chunk_ms[j] = ms;
+            const double egress = win > 0 && P > 1 ? (double)blk * 16 * (P - 1) / (win * 1e-3) / 1e9 : 0.0;
+            stats->rank_egress_gbps[i] = egress;
+            for (int q = 0; q < P; ++q) {
+                const double gbps = q == i ? (win > 0 ? (double)blk * 16 / (win * 1e-3) / 1e9 : 0.0) : egress / (P - 1);
+                stats->link_gbps[i][q] = gbps;
+                if (q != i && gbps > 0) { lmin = gbps < lmin ? gbps : lmin; lmax = gbps > lmax ? gbps : lmax; lsum += gbps; ++links; }
+            }
+            continue;
+        }
+        double first_ms = 1e300, last_ms = 0;                 // this rank's window over its inter-rank pairs, relative to e_p1e
         for (int q = 0; q < P; ++q) {
             double gbps = 0;
+            if (p->mode != SA_DIST_XCHG_FUSED && q != i) {
+                float a = 0, b = 0;
+                if (hipEventElapsedTime(&a, k.e_p1e, k.e_cs[q]) == hipSuccess && hipEventElapsedTime(&b, k.e_p1e, k.e_ce[q]) == hipSuccess) {
+                    if (a < first_ms) first_ms = a;
+                    if (b > last_ms) last_ms = b;
+                }
+            }
             if (p->mode != SA_DIST_XCHG_FUSED) {
                 if (hipEventElapsedTime(&ms, k.e_cs[q], k.e_ce[q]) == hipSuccess && ms > 0) {
                     gbps = (double)blk * 16 / (ms * 1e-3) / 1e9;
@@ -636,7 +673,15 @@ done:
             stats->link_gbps[i][q] = gbps;
             if (q != i && gbps > 0) { lmin = gbps < lmin ? gbps : lmin; lmax = gbps > lmax ? gbps : lmax; lsum += gbps; ++links; }
         }
+        if (p->mode == SA_DIST_XCHG_FUSED) {
+            if (hipEventElapsedTime(&ms, k.e_p1s, k.e_p1e) == hipSuccess) stats->rank_exchange_ms[i] = ms;
+        } else if (last_ms > first_ms) {
+            stats->rank_exchange_ms[i] = last_ms - first_ms;
+        }
+        if (stats->rank_exchange_ms[i] > 0 && P > 1)
+            stats->rank_egress_gbps[i] = (double)blk * 16 * (P - 1) / (stats->rank_exchange_ms[i] * 1e-3) / 1e9;
     }
+    stats->pairs_timed = p->mode == SA_DIST_XCHG_DMA || p->mode == SA_DIST_XCHG_KERNEL;
     stats->exchange_ms = p->mode == SA_DIST_XCHG_FUSED ? 0.0 : xmax;
     if (links) {
         stats->link_gbps_min = lmin; stats->link_gbps_max = lmax; stats->link_gbps_mean = lsum / links;

@@ -615,9 +615,9 @@ int sa_find_peaks_f64_noalloc_dev(const double* x, int64_t batch, int64_t n, dou
         set_error("find_peaks: need batch >= 0, n >= 1, max_peaks >= 1, distance >= 1");
         return SA_EINVAL;
     }
-    if ((uint64_t)batch * (uint64_t)max_peaks > (uint64_t)SA_NOALLOC_SCRATCH_BYTES) {
-        set_error("find_peaks_noalloc: batch * max_peaks = %lld exceeds the built-in scratch of %lld bytes; use "
-                  "sa_find_peaks_f64_dev with a work buffer", (long long)batch * max_peaks, (long long)SA_NOALLOC_SCRATCH_BYTES);
+    if (batch > (int64_t)SA_NOALLOC_SCRATCH_BYTES / max_peaks) {          // a division: the product can wrap
+        set_error("find_peaks_noalloc: batch = %lld x max_peaks = %d exceeds the built-in scratch of %lld bytes; use "
+                  "sa_find_peaks_f64_dev with a work buffer", (long long)batch, (int)max_peaks, (long long)SA_NOALLOC_SCRATCH_BYTES);
         return SA_EUNSUP;
     }
     uint8_t* work = nullptr;

@@ -35,8 +35,9 @@ struct Worker {
 // leaked on purpose (like runtime.hip's thread-state pool): the workers are detached and may outlive static destruction
 struct Pool {
     std::mutex dispatch;                   // one sharded call at a time; concurrent callers queue here
-    std::mutex cfg;                        // guards `workers`
+    std::mutex cfg;                        // guards `workers` and `devices`
     std::vector<Worker*> workers;
+    std::vector<int> devices;              // the configured fan-out; survives sa_shutdown (workers restart on the next sharded call)
 };
 Pool& pool() {
     static Pool* p = new Pool;
@@ -81,12 +82,33 @@ void stop_workers_locked(Pool& p) {         // p.cfg held
     p.workers.clear();
 }
 
+// p.cfg held: one detached thread per configured device; SA_EHIP (+ message) when a thread cannot be started
+int start_workers_locked(Pool& p) {
+    for (int dev : p.devices) {
+        Worker* w = new Worker;
+        w->dev = dev;
+        try {
+            std::thread(worker_main, w).detach();
+        } catch (...) {                                    // no exception may cross the C ABI
+            delete w;
+            stop_workers_locked(p);
+            set_error("sa_shard_devices: could not start a worker thread");
+            return SA_EHIP;
+        }
+        p.workers.push_back(w);
+    }
+    return SA_OK;
+}
+
 }  // namespace
 
+// The configured fan-out.  sa_shutdown stops the worker threads (they own streams and staging arenas) but keeps the device
+// list, and the next sharded call starts them again: a process that shuts the library down and goes on using it keeps
+// its multi-GPU fan-out.
 int shard_count() {
     Pool& p = pool();
     std::lock_guard<std::mutex> l(p.cfg);
-    return (int)p.workers.size();
+    return (int)p.devices.size();
 }
 
 void shard_shutdown() {
@@ -111,20 +133,11 @@ int shard_configure(const int32_t* devices, int32_t count) {
     std::lock_guard<std::mutex> d(p.dispatch);            // no sharded call is in flight while the pool changes
     std::lock_guard<std::mutex> l(p.cfg);
     stop_workers_locked(p);
-    for (int i = 0; i < count; ++i) {
-        Worker* w = new Worker;
-        w->dev = devices ? devices[i] : i % ndev;
-        try {
-            std::thread(worker_main, w).detach();
-        } catch (...) {                                    // no exception may cross the C ABI
-            delete w;
-            stop_workers_locked(p);
-            set_error("sa_shard_devices: could not start a worker thread");
-            return SA_EHIP;
-        }
-        p.workers.push_back(w);
-    }
-    return SA_OK;
+    p.devices.clear();
+    for (int i = 0; i < count; ++i) p.devices.push_back(devices ? devices[i] : i % ndev);
+    const int rc = start_workers_locked(p);
+    if (rc != SA_OK) p.devices.clear();
+    return rc;
 }
 
 // Contiguous block of `total` items owned by shard s of g (the first total % g shards get one more) — the same
@@ -142,6 +155,7 @@ int run_sharded(int64_t total, const std::function<int(int64_t, int64_t)>& fn) {
     std::vector<Worker*> ws;
     {
         std::lock_guard<std::mutex> l(p.cfg);
+        if (p.workers.empty() && !p.devices.empty()) SA_TRY(start_workers_locked(p));   // first sharded call after sa_shutdown
         ws = p.workers;
     }
     const int g = (int)ws.size();

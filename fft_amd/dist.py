@@ -122,21 +122,18 @@ class DistPlan:
         self._lib.check(self.lib.sa_dist_plan_info(self._h, rank, self._C.byref(inf)))
         return inf
 
-    def _on(self, rank):
-        self._lib.check(self.lib.sa_set_device(self.info[rank].device))
-
     def upload(self, rank, slab):
         """Host complex128 array (slab_elems values, any shape) -> rank's input slab."""
         slab = np.ascontiguousarray(slab, dtype=np.complex128)
         if slab.size != self.info[rank].slab_elems:
             raise ValueError(f"rank {rank}: slab has {slab.size} values, expected {self.info[rank].slab_elems}")
-        self._on(rank)
+        # plain hipMemcpy under unified addressing: the copy finds the slab's device by itself, and the calling thread's
+        # current device is left alone (ADVICE r2: switching it here sent the caller's later calls to the last rank's GPU)
         self._lib.check(self.lib.sa_memcpy_h2d(self.info[rank].in_, self._lib.ptr(slab), slab.nbytes))
 
     def download(self, rank):
         """Rank's output slab as a host complex128 vector of slab_elems values."""
         out = np.empty(self.info[rank].slab_elems, dtype=np.complex128)
-        self._on(rank)
         self._lib.check(self.lib.sa_memcpy_d2h(self._lib.ptr(out), self.info[rank].out, out.nbytes))
         return out
 
@@ -171,9 +168,8 @@ class DistPlan:
         st = self._lib.DistStats()
         self._lib.check(self.lib.sa_dist_execute(self._h, self._C.byref(st)))
         P = self.n_ranks
-        d = {k: getattr(st, k) for k, _ in st._fields_ if k not in ("link_gbps", "reserved")}
+        d = _stats_dict(st, P)
         d["exchange_mode"] = self.exchange
-        d["link_gbps"] = [[st.link_gbps[i][q] for q in range(P)] for i in range(P)]
         return d
 
     def close(self):
@@ -205,7 +201,18 @@ def fft_dist(x, n_ranks=0, exchange="auto", chunks=0):
     st = _lib.DistStats()
     flags = _lib.DIST_XCHG_NAMES[exchange] << 4 | int(chunks) << 8
     _lib.check(lib.sa_fft_c2c_f64_dist(_lib.ptr(x), _lib.ptr(out), x.size, int(n_ranks), flags, C.byref(st)))
-    return out, {k: getattr(st, k) for k, _ in st._fields_ if k not in ("link_gbps", "reserved")}
+    return out, _stats_dict(st, st.n_ranks)
+
+
+def _stats_dict(st, P):
+    """sa_dist_stats -> dict; the fixed-size arrays are cut to the plan's rank / chunk count."""
+    arrays = ("link_gbps", "rank_exchange_ms", "rank_egress_gbps", "chunk_ms")
+    d = {k: getattr(st, k) for k, _ in st._fields_ if k not in arrays}
+    d["link_gbps"] = [[st.link_gbps[i][q] for q in range(P)] for i in range(P)]
+    d["rank_exchange_ms"] = [st.rank_exchange_ms[i] for i in range(P)]
+    d["rank_egress_gbps"] = [st.rank_egress_gbps[i] for i in range(P)]
+    d["chunk_ms"] = [st.chunk_ms[j] for j in range(min(st.n_chunks, 16))]
+    return d
 
 
 # ---- host helpers for tests / small problems ---------------------------------------------------------

@@ -186,7 +186,10 @@ typedef struct sa_dist_info {
 } sa_dist_info;
 typedef struct sa_dist_stats {
     int64_t n, bytes_per_peer;  /* bytes each rank sends to each other rank in the main exchange: 16 n / P^2    */
-    int32_t n_ranks, n_devices, exchange_mode, n_chunks, exchanges /* all-to-alls run: 1, 2 or 3 */, reserved;
+    int32_t n_ranks, n_devices, exchange_mode, n_chunks, exchanges /* all-to-alls run: 1, 2 or 3 */;
+    int32_t pairs_timed;        /* 1: link_gbps[p][q] is that pair's own copy time (DMA, KERNEL); 0: the pairs of a source are
+                                   not timed apart (RCCL: one group per chunk; FUSED: the stores of pass 1) and every
+                                   link_gbps[p][q], q != p, holds the source's egress divided evenly over its P-1 links  */
     double  total_ms;           /* host wall clock of the call                                                  */
     double  device_ms;          /* longest first-event -> last-event span of any rank                           */
     double  pass1_ms, phase2_ms;/* longest first pass / longest owner phase of any rank (HIP events)            */
@@ -195,6 +198,9 @@ typedef struct sa_dist_stats {
     double  aggregate_gbps;     /* all inter-rank bytes / exchange_ms (FUSED: / pass1_ms)                       */
     double  link_gbps[SA_DIST_MAX_RANKS][SA_DIST_MAX_RANKS]; /* [source][owner]: bytes_per_peer / that pair's copy time
                                    (FUSED: / the source's pass-1 time, a lower bound); diagonal = local copies */
+    double  rank_exchange_ms[SA_DIST_MAX_RANKS]; /* per source rank: first copy / first RCCL group start -> last one's end   */
+    double  rank_egress_gbps[SA_DIST_MAX_RANKS]; /* bytes_per_peer (P-1) / rank_exchange_ms: what left that GPU over xGMI   */
+    double  chunk_ms[SA_DIST_MAX_RANKS];         /* RCCL: longest time any rank spent in the group of chunk j (j < 16); else 0 */
 } sa_dist_stats;
 int sa_dist_plan_create(sa_dist_plan** plan, int64_t n, int32_t n_ranks, const int32_t* devices, int32_t flags);
 int sa_dist_plan_info(const sa_dist_plan* plan, int32_t rank, sa_dist_info* info);

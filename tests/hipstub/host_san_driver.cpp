@@ -195,9 +195,32 @@ int main() {
                 std::vector<int32_t> pb(4);
                 while (!stop.load()) CHECK(sa_rfft_peak_f32(x.data(), 4, 2048, 1 + t % 3, 0.0, 0, nullptr, pb.data(), pm.data()) == SA_OK);
             });
+        // ... and a thread looping over a distributed plan: sa_dist_execute fetches cached twiddle tables that sa_shutdown
+        // frees, so it must sit behind the same gate; a sharded caller whose workers sa_shutdown stops
+        th.emplace_back([&stop] {
+            sa_dist_plan* pl = nullptr;
+            CHECK(sa_dist_plan_create(&pl, 1 << 14, 4, nullptr, SA_DIST_XCHG(SA_DIST_XCHG_DMA) | SA_DIST_CHUNKS(2)) == SA_OK);
+            if (!pl) return;
+            sa_dist_stats st;
+            double err = 0;
+            while (!stop.load()) {
+                CHECK(sa_dist_fill(pl, SA_DIST_KAT_IMPULSE, 5, 0) == SA_OK);
+                CHECK(sa_dist_execute(pl, &st) == SA_OK && st.pairs_timed == 1);
+                CHECK(sa_dist_check(pl, SA_DIST_KAT_IMPULSE, 5, &err) == SA_OK);
+            }
+            CHECK(sa_dist_plan_destroy(pl) == SA_OK);
+        });
+        CHECK(sa_shard_devices(nullptr, 3) == SA_OK);
+        th.emplace_back([&stop] {
+            std::vector<float> x(16 * 1024, 1.f), pm(16);
+            std::vector<int32_t> pb(16);
+            while (!stop.load()) CHECK(sa_rfft_peak_f32(x.data(), 16, 1024, 1, 0.0, 0, nullptr, pb.data(), pm.data()) == SA_OK);
+        });
         for (int r = 0; r < 50; ++r) sa_shutdown();
         stop = true;
         for (auto& t : th) t.join();
+        CHECK(sa_shard_count() == 3);                     // the configured fan-out survives sa_shutdown
+        CHECK(sa_shard_devices(nullptr, 0) == SA_OK && sa_shard_count() == 0);
     }
     sa_shutdown();
     CHECK(hipstub_launches() > 100);

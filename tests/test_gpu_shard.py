@@ -108,3 +108,19 @@ def test_shard_errors_and_concurrency():
         _same(o, r)
     # reconfiguring and switching off leaves no worker behind
     assert fft_amd.set_shard_devices(2) == 2 and fft_amd.set_shard_devices(None) == 0
+
+
+def test_fan_out_survives_shutdown():
+    """sa_shutdown stops the shard workers but keeps the configured device list; the next sharded call restarts them
+    (a process that shut the library down silently fell back to one GPU)."""
+    lib = _lib.load()
+    x = np.random.default_rng(3).standard_normal((101, 2048)).astype(np.float32)
+    fft_amd.set_shard_devices(0)
+    ref = fft_amd.rfft_peak(x, "hann")
+    assert fft_amd.set_shard_devices([0, 0, 0]) == 3
+    lib.sa_shutdown()
+    assert lib.sa_shard_count() == 3
+    _same(fft_amd.rfft_peak(x, "hann"), ref)
+    lib.sa_shutdown()
+    _same(fft_amd.rfft_peak(x, "hann"), ref)
+    assert fft_amd.set_shard_devices(0) == 0
