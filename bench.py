@@ -76,12 +76,20 @@ def main():
     ap.add_argument("--log2-batch", type=int, default=20, help="frames per GPU = 2^k (default 2^20 = config C2)")
     ap.add_argument("--peak-only", action="store_true", help="mode B: no spectrum written")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extra-child", default="", help=argparse.SUPPRESS)     # internal: run one group of extra legs, print its JSON
+    ap.add_argument("--extra-timeout", type=float, default=420.0, help="seconds an extra-leg child process may take before it is abandoned")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C4 / C5 legs (N = 1) and the distributed-FFT report (N > 1)")
+    ap.add_argument("--c5-log2n", type=int, default=30, help="length of the C5 transforms in the extra legs (default 2^30)")
+    ap.add_argument("--c3-log2-samples", type=int, default=30, help="stereo sample-frames of the C3 leg (default 2^30)")
+    ap.add_argument("--c4-batch", type=int, default=65536, help="parameter records of the C4 leg (default 65 536)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="rendezvous, barrier and max-over-ranks only (no GPU work, value = null): CPU test of the launch path")
     args = ap.parse_args()
 
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
+    if args.extra_child:
+        return extra_child_main(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes now, before this process
         # has imported torch or touched the GPU (a process that has initialised the GPU must never exec another program),
@@ -117,8 +125,12 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"metric": "plumbing only (no GPU work)", "value": None, "unit": "spectra/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "max_rank_elapsed": elapsed}))
+            line = {"metric": "plumbing only (no GPU work)", "value": None, "unit": "spectra/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "max_rank_elapsed": elapsed}
+            if world > 1 and not args.no_extra:
+                # the same call the real N > 1 run makes after its timed region; without a GPU every entry is an `error`
+                line["extra"] = run_extra_child("dist", args, world, True)
+            print(json.dumps(line))
         return
 
     from fft_amd import _lib
@@ -186,13 +198,22 @@ def main():
     if rank == 0:
         # sanity: a sample of frames vs the CPU oracle (not timed)
         from oracle import spectrum_oracle as O
-        ns = 256
-        xs = np.empty((ns, n), np.float32); dx.download(xs, ns * n * 4)
-        pbs = np.empty(ns, np.int32); dpb.download(pbs, ns * 4)
+        # first 192 and LAST 64 frames of the launch (the last, ragged one-shot workgroup of 2^20 / 3 included)
+        ns, nl = 256, min(64, batch // 2)
+        nh = ns - nl
+        xs = np.empty((ns, n), np.float32)
+        dx.download(xs[:nh], nh * n * 4)
+        dx.download(xs[nh:], nl * n * 4, (batch - nl) * n * 4)
+        pbs = np.empty(ns, np.int32)
+        dpb.download(pbs[:nh], nh * 4)
+        dpb.download(pbs[nh:], nl * 4, (batch - nl) * 4)
         mref, pbref, _ = O.rfft_mag_peak(xs, "hann")
         parity_ok = bool((pbs == pbref).all())
         if not args.peak_only:
-            ms_ = np.empty((ns, n // 2 + 1), np.float32); dm.download(ms_, ms_.nbytes)
+            nb_ = n // 2 + 1
+            ms_ = np.empty((ns, nb_), np.float32)
+            dm.download(ms_[:nh], nh * nb_ * 4)
+            dm.download(ms_[nh:], nl * nb_ * 4, (batch - nl) * nb_ * 4)
             err = float((np.linalg.norm(ms_ - mref, axis=1) / np.linalg.norm(mref, axis=1)).max())
             parity_ok = parity_ok and err < 1e-5 * 12
         out = {
@@ -219,10 +240,143 @@ def main():
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(xs if ns >= 2048 else _more_frames(dx, n))
-        print(json.dumps(out))
+    # the headline is measured: release its buffers before anything else runs on the GPUs
+    for b in (dx, dm, dpb, dpm):
+        b.free()
     if dist is not None:
-        dist.barrier()
+        dist.barrier()                                          # every rank has let go of its device memory
         dist.destroy_process_group()
+    if rank != 0:
+        return
+    if not args.no_extra:
+        # The extra legs run in a CHILD process with a time limit: a hang or a crash in one of them (the multi-device legs
+        # have never met real xGMI links) costs an `error` entry, never the headline line.  N = 1: C3 / C4 / C5 on this GPU;
+        # N > 1: the child alone drives all N GPUs through the library's one-process distributed FFT and fan-out.
+        out["extra"].update(run_extra_child("secondary" if world == 1 else "dist", args, world, share))
+    print(json.dumps(out))
+
+
+def run_extra_child(kind, args, world, share):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--extra-child", kind, "--gpus", str(world), "--c5-log2n", str(args.c5_log2n),
+           "--c3-log2-samples", str(args.c3_log2_samples), "--c4-batch", str(args.c4_batch)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                            "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["SA_BENCH_SHARE_GPU"] = "1" if share else "0"
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    except OSError as e:
+        return {"error": f"extra legs: could not start the child process: {e}"}
+    try:
+        so, se = proc.communicate(timeout=args.extra_timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        try:
+            proc.communicate(timeout=15)
+        except Exception:                                       # noqa: BLE001 — an unkillable child is left behind, not waited for
+            pass
+        return {"error": f"extra legs ({kind}): no result within {args.extra_timeout:.0f} s, child abandoned"}
+    for ln in reversed(so.splitlines()):
+        try:
+            j = json.loads(ln)
+        except ValueError:
+            continue
+        if isinstance(j, dict):
+            return j
+    return {"error": f"extra legs ({kind}): child exit code {proc.returncode}, no JSON; stderr tail: {se[-400:]}"}
+
+
+def extra_child_main(args):
+    """`bench.py --extra-child secondary|dist`: one group of extra legs in a process of its own; prints one JSON dict."""
+    share = os.environ.get("SA_BENCH_SHARE_GPU") == "1"
+    res = {}
+    try:
+        from fft_amd import _lib
+        lib = _lib.load()
+        if args.extra_child == "secondary":
+            _lib.check(lib.sa_init(0))
+            res = secondary_configs(lib, args)
+        else:
+            devs = [0] * args.gpus if share else list(range(args.gpus))
+            res = {"c5_dist": c5_dist_report(args.gpus, devs, args.c5_log2n), "shard_fan_out": shard_fan_out_report(args.gpus, devs)}
+    except Exception as e:                                      # noqa: BLE001
+        res["error"] = f"{type(e).__name__}: {e}"
+    print(json.dumps(res), flush=True)
+
+
+def secondary_configs(lib, args):
+    """N = 1: BASELINE configs C3, C4 and C5 on the same GPU in the same run — SURVEY §8(d) inputs generated on the device,
+    HIP-event timing, algorithmic bytes, and a sampled check against the oracle each (tools/bench_legs.py).  A leg that
+    fails reports {"error": ...}."""
+    from tools import bench_legs as L
+    return {
+        "c3_stft": L.run_leg(lambda: L.C3(lib, args.c3_log2_samples), 3),
+        "c4_pipeline": L.run_leg(lambda: L.C4(lib, args.c4_batch), 3),
+        "c5_fft_1gpu": L.run_leg(lambda: L.C5(lib, args.c5_log2n), 3),
+    }
+
+
+def c5_dist_report(n_ranks, devices, log2n):
+    """N > 1: the 2^log2n fp64 FFT over n_ranks ranks driven by THIS process (csrc/dist_fft.hip), once per exchange mode:
+    impulse + tone known answers checked on the devices (for FUSED across devices this is the coherence self-check of
+    the peer stores), then a timed run on N(0,1) input with the exchange's per-GPU egress and per-link GB/s.  Every entry
+    is {exchange, chunks, ...numbers} or {exchange, chunks, error}."""
+    report = []
+    n = 1 << log2n
+    for exchange, chunks in (("rccl", 1), ("rccl", 4), ("dma", 4), ("kernel", 4), ("fused", 1)):
+        entry = {"exchange": exchange, "chunks": chunks, "n_ranks": n_ranks, "log2n": log2n}
+        plan = None
+        try:
+            from fft_amd.dist import DistPlan
+            plan = DistPlan(n, n_ranks, devices=devices, exchange=exchange, chunks=chunks)
+            kat = 0.0
+            for kind, param, scale in (("impulse", 123456789 % n, 1.0), ("tone", 987654321 % n, float(n))):
+                plan.fill(kind, param)
+                plan.execute()
+                kat = max(kat, plan.check(kind, param) / scale)
+            plan.fill("noise", 0, 0x5EED0005)
+            plan.execute()                                      # warm
+            st = min((plan.execute() for _ in range(3)), key=lambda d: d["device_ms"])
+            eg = [v for v in st["rank_egress_gbps"] if v > 0]
+            entry.update({"kat_err": kat, "kat_ok": bool(kat < 1e-12), "ms": st["device_ms"], "host_ms": st["total_ms"],
+                          "pass1_ms": st["pass1_ms"], "exchange_ms": st["exchange_ms"], "phase2_ms": st["phase2_ms"],
+                          "bytes_per_peer": st["bytes_per_peer"], "n_devices": st["n_devices"], "pairs_timed": bool(st["pairs_timed"]),
+                          "link_gbps_min": st["link_gbps_min"], "link_gbps_mean": st["link_gbps_mean"], "link_gbps_max": st["link_gbps_max"],
+                          "egress_gbps_per_gpu_min": min(eg) if eg else 0.0, "egress_gbps_per_gpu_max": max(eg) if eg else 0.0,
+                          "aggregate_gbps": st["aggregate_gbps"], "chunk_ms": st["chunk_ms"],
+                          "points_per_s": n / (st["device_ms"] * 1e-3)})
+        except Exception as e:                                  # noqa: BLE001
+            entry["error"] = f"{type(e).__name__}: {e}"
+        finally:
+            if plan is not None:
+                plan.close()
+        report.append(entry)
+    return report
+
+
+def shard_fan_out_report(n_shards, devices, log2_frames=15, n=N_POINTS):
+    """N > 1: the one-process fan-out of the HOST-pointer entry point (sa_shard_devices, csrc/shard.hip) on a host batch:
+    PCIe-inclusive spectra/s with 1 and with N shard devices (never the headline `value`)."""
+    try:
+        import fft_amd
+        frames = 1 << log2_frames
+        x = np.random.default_rng(1).standard_normal((frames, n)).astype(np.float32)
+        res = {"frames": frames, "n": n, "devices": devices}
+        for label, devs in (("one_device", 0), ("all_devices", devices)):
+            fft_amd.set_shard_devices(devs)
+            fft_amd.rfft_peak(x[:256], "hann")
+            t0 = time.perf_counter()
+            _, pb, _ = fft_amd.rfft_peak(x, "hann")
+            dt = time.perf_counter() - t0
+            res[label + "_spectra_per_s"] = frames / dt
+            if label == "one_device":
+                ref = pb
+            else:
+                res["bit_identical_peaks"] = bool((pb == ref).all())
+        fft_amd.set_shard_devices(0)
+        return res
+    except Exception as e:                                      # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def _launch_ranks(n_gpus):

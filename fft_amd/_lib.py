@@ -47,6 +47,11 @@ PROTOTYPES = {
     "sa_time_rfft_peak_f32_dev": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _i32,
                                             C.POINTER(C.c_float)]),
     "sa_fill_tone_noise_f32_dev": (C.c_int, [_vp, _i64, _i32, _dbl, _u64, _vp]),
+    "sa_timer_start": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "sa_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "sa_c2c_kat_fill_dev": (C.c_int, [_vp, _i64, _i32, _i64, _u64, _vp]),
+    "sa_c2c_kat_check_dev": (C.c_int, [_vp, _i64, _i32, _i64, C.POINTER(_dbl), _vp]),
+    "sa_fill_pcm16_stereo_dev": (C.c_int, [_vp, _i64, _dbl, _u64, _vp]),
     "sa_fft_c2c_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i32]),
     "sa_fft_c2c_f64_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "sa_dist_plan_create": (C.c_int, [C.POINTER(_vp), _i64, _i32, _vp, _i32]),

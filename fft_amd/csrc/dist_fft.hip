@@ -462,6 +462,45 @@ int sa_dist_check(sa_dist_plan* p, int32_t kind, int64_t param, double* max_abs_
     return SA_OK;
 }
 
+// The same analytic inputs / checks for ONE natural-order vector on the current device (the single-GPU engine's C5 KATs).
+static sa::DistLayout single_layout(int64_t n) {
+    sa::DistLayout l;
+    l.n = n; l.S = n; l.Sp = n; l.R1 = 1; l.K1L = 1; l.natural = 1; l.rank = 0;
+    return l;
+}
+int sa_c2c_kat_fill_dev(double* x, int64_t n, int32_t kind, int64_t param, uint64_t seed, void* stream) {
+    using namespace sa;
+    SA_ENTER();
+    if (!x || n < 1 || kind < SA_DIST_KAT_IMPULSE || kind > SA_DIST_KAT_NOISE || (kind != SA_DIST_KAT_NOISE && (param < 0 || param >= n))) {
+        set_error("sa_c2c_kat_fill_dev: bad arguments (n=%lld kind=%d param=%lld)", (long long)n, kind, (long long)param);
+        return SA_EINVAL;
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : thread_stream();
+    hipLaunchKernelGGL(dist_fill_kernel, dim3(copy_grid(n)), dim3(256), 0, st, reinterpret_cast<Cd*>(x), n, single_layout(n), kind, param, seed);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+int sa_c2c_kat_check_dev(const double* X, int64_t n, int32_t kind, int64_t param, double* max_abs_err, void* stream) {
+    using namespace sa;
+    SA_ENTER();
+    if (!X || !max_abs_err || n < 1 || (kind != SA_DIST_KAT_IMPULSE && kind != SA_DIST_KAT_TONE) || param < 0 || param >= n) {
+        set_error("sa_c2c_kat_check_dev: bad arguments (only the impulse and tone inputs have closed-form spectra)");
+        return SA_EINVAL;
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : thread_stream();
+    Temp tmp;
+    unsigned long long* derr = static_cast<unsigned long long*>(tmp.dev(8));
+    if (!derr) return SA_ENOMEM;
+    SA_HIP(hipMemsetAsync(derr, 0, 8, st));
+    hipLaunchKernelGGL(dist_check_kernel, dim3(copy_grid(n)), dim3(256), 0, st, reinterpret_cast<const Cd*>(X), n, single_layout(n), kind, param, derr);
+    SA_HIP(hipGetLastError());
+    unsigned long long bits = 0;
+    SA_HIP(hipMemcpyAsync(&bits, derr, 8, hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    memcpy(max_abs_err, &bits, 8);
+    return SA_OK;
+}
+
 int sa_dist_execute(sa_dist_plan* p, sa_dist_stats* stats) {
     using namespace sa;
     // the guard keeps sa_shutdown from freeing the cached twiddle tables (get_cached_table) under the kernels queued below

@@ -480,6 +480,43 @@ int sa_memcpy_d2h(void* dst, const void* src, uint64_t bytes) {
 }
 int sa_thread_state_count(void) { return sa::thread_state_count(); }
 
+namespace { struct StreamTimer { hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr; int dev = 0; }; }
+
+int sa_timer_start(void* stream, void** timer) {
+    SA_ENTER();
+    if (!timer) { sa::set_error("sa_timer_start: timer is NULL"); return SA_EINVAL; }
+    *timer = nullptr;
+    StreamTimer* t = new StreamTimer;
+    t->st = stream ? (hipStream_t)stream : sa::thread_stream();
+    hipError_t e = hipGetDevice(&t->dev);
+    if (e == hipSuccess) e = hipEventCreate(&t->e0);
+    if (e == hipSuccess) e = hipEventCreate(&t->e1);
+    if (e == hipSuccess) e = hipEventRecord(t->e0, t->st);
+    if (e != hipSuccess) {
+        sa::set_error("sa_timer_start: %s", hipGetErrorString(e));
+        if (t->e0) (void)hipEventDestroy(t->e0);
+        if (t->e1) (void)hipEventDestroy(t->e1);
+        delete t;
+        return SA_EHIP;
+    }
+    *timer = t;
+    return SA_OK;
+}
+
+int sa_timer_stop(void* timer, float* ms) {
+    SA_ENTER();
+    if (!timer || !ms) { sa::set_error("sa_timer_stop: NULL argument"); return SA_EINVAL; }
+    StreamTimer* t = static_cast<StreamTimer*>(timer);
+    hipError_t e = hipEventRecord(t->e1, t->st);
+    if (e == hipSuccess) e = hipEventSynchronize(t->e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, t->e0, t->e1);
+    (void)hipEventDestroy(t->e0);
+    (void)hipEventDestroy(t->e1);
+    delete t;
+    if (e != hipSuccess) { sa::set_error("sa_timer_stop: %s", hipGetErrorString(e)); return SA_EHIP; }
+    return SA_OK;
+}
+
 int sa_sync(void) {
     SA_ENTER();
     SA_HIP(hipStreamSynchronize(sa::thread_stream()));

@@ -388,7 +388,48 @@ int stft_pcm16_dev(const int16_t* pcm, int64_t n_samples, int32_t channels, int3
 
 }  // namespace sa
 
+namespace sa {
+// SURVEY §8(d) C3 synthetic recording (include/specengine.h: sa_fill_pcm16_stereo_dev).  Phases are reduced to a fraction of
+// a cycle in fp64 before the sine (t reaches 2.4e4 s at 2^30 samples); the noise is counter-based, so any span can be
+// regenerated independently.
+__device__ __forceinline__ uint64_t pcm_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) fill_pcm16_stereo_kernel(int16_t* __restrict__ pcm, int64_t n_samples, double fs, uint64_t seed) {
+    constexpr int64_t SWEEP = 1 << 20;
+    const double f0 = 100.0, f1 = 20000.0;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < n_samples; n += (int64_t)gridDim.x * 256) {
+        const double dn = (double)n, dm = (double)(n & (SWEEP - 1));
+        const double c1 = 440.0 * dn / fs, c2 = 3000.0 * dn / fs;
+        const double c3 = (f0 * dm + (f1 - f0) * dm * dm / (2.0 * (double)SWEEP)) / fs;
+        const double l = 0.35 * sinpi(2.0 * (c1 - floor(c1))) + 0.25 * sinpi(2.0 * (c2 - floor(c2))) + 0.25 * sinpi(2.0 * (c3 - floor(c3)));
+        double r = 0.0;
+#pragma unroll
+        for (int o = 0; o < 12; ++o) {
+            const uint64_t h = pcm_mix64(seed ^ ((uint64_t)o << 56) ^ (uint64_t)(n >> o));
+            r += (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+        }
+        r *= 0.08;
+        const double ls = fmin(fmax(rint(l * 32767.0), -32768.0), 32767.0), rs = fmin(fmax(rint(r * 32767.0), -32768.0), 32767.0);
+        const short2 v = make_short2((short)ls, (short)rs);
+        reinterpret_cast<short2*>(pcm)[n] = v;
+    }
+}
+}  // namespace sa
+
 extern "C" {
+
+int sa_fill_pcm16_stereo_dev(int16_t* interleaved, int64_t n_samples, double fs, uint64_t seed, void* stream) {
+    SA_ENTER();
+    if (!interleaved || n_samples < 0 || !(fs > 0) || ((uintptr_t)interleaved & 3)) { sa::set_error("sa_fill_pcm16_stereo_dev: bad arguments"); return SA_EINVAL; }
+    if (n_samples == 0) return SA_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : sa::thread_stream();
+    const int64_t nb = (n_samples + 255) / 256, cap = (int64_t)sa::num_cus() * 16;
+    hipLaunchKernelGGL(sa::fill_pcm16_stereo_kernel, dim3((unsigned)(nb < cap ? nb : cap)), dim3(256), 0, st, interleaved, n_samples, fs, seed);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
 
 int64_t sa_stft_num_frames(int64_t n_samples, int32_t nfft, int32_t hop) {
     if (hop < 1 || nfft < 1 || n_samples < nfft) return 0;

@@ -135,6 +135,14 @@ int sa_time_rfft_peak_f32_dev(const float* x, int64_t batch, int32_t n, int32_t 
  * Same formula is restated on the host in oracle/ for parity tests. */
 int sa_fill_tone_noise_f32_dev(float* x, int64_t batch, int32_t n, double fs, uint64_t seed, void* stream);
 
+/* HIP-event timer on a stream (bench.py's roofline legs for the entry points that have no sa_time_* form; the reference's
+ * only timing is one time.time() log line, sab10.py:614, 659).  sa_timer_start records an event on `stream` (NULL = the
+ * calling thread's library stream — the one the *_dev entry points use when THEIR stream argument is NULL) and returns a
+ * handle; sa_timer_stop records the closing event on the same stream, waits for it, returns the elapsed milliseconds
+ * between the two events and releases the handle. */
+int sa_timer_start(void* stream, void** timer);
+int sa_timer_stop(void* timer, float* ms);
+
 /* ---- a6 for lengths outside the batched rfft kernels, and BASELINE config 5 --------------------
  * Complex-to-complex fp64 FFT, interleaved (re, im), unnormalised forward e^{-2 pi i k n/N}
  * (scipy.fft.fft, main.py:475); flags bit0 = inverse (conjugate transform scaled by 1/n, scipy.fft.ifft),
@@ -147,6 +155,11 @@ int sa_fill_tone_noise_f32_dev(float* x, int64_t batch, int32_t n, double fs, ui
 int sa_fft_c2c_f64(const double* in_ri, double* out_ri, int64_t n, int64_t batch, int32_t flags);
 int sa_fft_c2c_f64_dev(const double* in_ri, double* out_ri, double* work, int64_t n, int64_t batch,
                        int32_t flags, void* stream);
+/* Analytic inputs / closed-form checks for ONE device-resident vector in natural order (SURVEY §8(d) C5 known answers at
+ * sizes no host buffer should hold): kinds SA_DIST_KAT_* below (IMPULSE at index `param`, TONE at bin `param`, NOISE keyed by
+ * seed).  sa_c2c_kat_check_dev synchronises `stream` and returns max |X[k] - expected| over all n bins. */
+int sa_c2c_kat_fill_dev(double* x_ri, int64_t n, int32_t kind, int64_t param, uint64_t seed, void* stream);
+int sa_c2c_kat_check_dev(const double* X_ri, int64_t n, int32_t kind, int64_t param, double* max_abs_err, void* stream);
 
 /* ---- BASELINE config 5 across GPUs: ONE fp64 complex FFT of n = 2^L points as a distributed four-step --------------
  * No counterpart in the reference (single process, CPU: SURVEY §0); the arithmetic is scipy.fft.fft's (main.py:475).
@@ -282,6 +295,12 @@ int sa_stft_pcm16(const int16_t* interleaved, int64_t n_samples, int32_t channel
 int sa_stft_pcm16_dev(const int16_t* interleaved, int64_t n_samples, int32_t channels, int32_t nfft, int32_t hop,
                       int32_t window, double win_param, int32_t flags, float* mag, int32_t* peak_bin,
                       float* peak_mag, float* scratch, void* stream);
+/* Synthetic stereo recording generated on the device, interleaved [n_samples][2] int16:
+ *   L = 0.35 sin(2 pi 440 t) + 0.25 sin(2 pi 3000 t) + 0.25 sin(2 pi phi(t)), phi a linear sweep 100 Hz -> 20 kHz that
+ *       restarts every 2^20 samples;   R = pink-ish noise: 0.08 x the sum of 12 octave-held uniform(-1, 1) streams
+ *       (Voss-McCartney), counter-based and keyed by (seed, octave, n >> octave);   t = n / fs.
+ * No reference counterpart (the reference has no RIFF audio); parity tests read the samples back. */
+int sa_fill_pcm16_stereo_dev(int16_t* interleaved, int64_t n_samples, double fs, uint64_t seed, void* stream);
 
 /* ---- BASELINE config 4: fused generator pipeline, fp32 spectra, no HBM input ------------------------
  * Per parameter record:  synthesis + AM/FM at n_base points (main.py:460-472, 536-629; the record's N is

@@ -2,8 +2,20 @@
 import numpy as np
 import pytest
 
+import _escapes
 from fft_amd import specengine as S
 from oracle import spectrum_oracle as O
+
+
+def peak_ok(pb, pbref, mref, site):
+    """exact, or — recorded — one of the oracle's top two when they are within 1e-4 of each other (fp32 pipeline)"""
+    _escapes.compared(1)
+    if pb == pbref:
+        return True
+    if O.top2_gap(mref[None])[0] < 1e-4:
+        _escapes.note("test_gpu_pipeline." + site, 1)
+        return True
+    return False
 
 pytestmark = pytest.mark.gpu
 
@@ -30,8 +42,7 @@ def test_pipeline_matches_oracle(n_base, upsample):
         assert np.abs(y[i] - yu).max() < 2e-5, (i, np.abs(y[i] - yu).max())          # fp32 samples, O(1) amplitude
         rel = np.linalg.norm(mag[i] - mref) / np.linalg.norm(mref)
         assert rel < 1e-5 * np.log2(n), (i, rel)
-        if pb[i] != pbref:
-            assert O.top2_gap(mref[None])[0] < 1e-4
+        assert peak_ok(pb[i], pbref, mref, "matches_oracle")
         assert pm[i] == pytest.approx(pmref, rel=1e-3)
 
 
@@ -52,7 +63,7 @@ def test_pipeline_fm_sample_error_independent_of_modulation_index():
         worst.append(np.abs(y[i] - yu).max())
         assert worst[-1] < 2e-5, (i, p["fm_dev"] / p["Fm"], worst[-1])
         assert np.linalg.norm(mag[i] - mref) / np.linalg.norm(mref) < 1e-5 * 14
-        assert pb[i] == pbref or O.top2_gap(mref[None])[0] < 1e-4
+        assert peak_ok(pb[i], pbref, mref, "fm_index")
     assert max(worst[3:]) < 2.5 * max(worst[:2]) + 2e-6          # beta = 50 is no worse than beta <= 5
 
 
@@ -89,7 +100,7 @@ def test_pipeline_every_waveform_both_generator_classes_in_one_batch():
                                                        "Dente de Serra Modificado", "Passo (step)", "Tangente") and not p["fm_on"] else 0), (p["waveform"], int(bad.sum()))
         if not bad.any():
             assert np.linalg.norm(mag[i] - mref) / np.linalg.norm(mref) < 1e-5 * 14, p["waveform"]
-            assert pb[i] == pbref or O.top2_gap(mref[None])[0] < 1e-4, p["waveform"]
+            assert peak_ok(pb[i], pbref, mref, "every_waveform"), p["waveform"]
     # noise and the overflowing sinh: they run (heavy class) and leave finite / reference-like output
     pn = [dict(params[0], waveform="Ruído Branco", am_on=False, fm_on=False), dict(params[0], waveform="Seno", am_on=False, fm_on=False)]
     mag2, pb2, pm2, y2 = S.synth_analyze(pn, None, n_base, 8, "hann", return_signal=True)

@@ -4,6 +4,7 @@ import os
 import numpy as np
 import pytest
 
+import _escapes
 from oracle import spectrum_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -18,9 +19,11 @@ def check_peaks(pb, pm, mag_ref, pb_ref, excl=False, tie_rel=1e-5):
     """Peak bins must be identical to np.argmax on the oracle spectrum; a frame whose oracle top-2
     relative gap is below `tie_rel` (f32 rounding can legitimately flip it) must match one of the two."""
     bad = np.nonzero(pb != pb_ref)[0]
+    _escapes.compared(np.size(pb))
     if len(bad):
         gap = O.top2_gap(mag_ref[bad], excl)
         assert (gap < tie_rel).all(), f"peak mismatch on frames {bad[:8]} gaps {gap[:8]}"
+        _escapes.note("test_gpu_rfft.check_peaks", len(bad), f"frames {bad[:8]} gaps {gap[:8]}")
 
 
 @pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768])
@@ -381,3 +384,41 @@ def test_wave_kernel_variants_agree_bitwise(tmp_path):
             np.testing.assert_array_equal(z[k], ref[k], err_msg=f"{env} {k}")
         if env.get("SA_R4K_WH") != "6":
             np.testing.assert_array_equal(z["d"], ref["d"], err_msg=f"{env} d")     # (the dB kernel has no 4-wave form)
+
+
+@pytest.mark.parametrize("n", [4096, 1024, 8192])
+def test_exact_ties_name_the_lowest_bin_in_both_modes(n):
+    """Known answers whose magnitudes tie EXACTLY (every partial sum is exact in fp32), so np.argmax's lowest-index rule
+    is the whole answer: impulse at 0, n/4 and n/2 (|Y| = 1 on every bin), all-zero frames, a tone at n/4 against a
+    half-amplitude tone at Nyquist (|Y[n/4]| = |Y[n/2]| = n/2), DC against Nyquist.  Mode A (spectrum written) and mode B
+    (peak only; the 4096-point kernel orders bins by |Y|^2 there, rfft4096.h) must both name the oracle's bin — these
+    are the cases where the two orderings could part, and they do not (VERDICT r2 #6)."""
+    import fft_amd
+    t = np.arange(n)
+    frames = []
+    for j in (0, n // 4, n // 2):
+        x = np.zeros(n, np.float32); x[j] = 1.0
+        frames.append(x)
+    frames.append(np.zeros(n, np.float32))
+    frames.append((np.cos(np.pi * t / 2).round() + 0.5 * np.cos(np.pi * t).round()).astype(np.float32))
+    frames.append((1.0 + np.cos(np.pi * t).round()).astype(np.float32))
+    frames.append((np.cos(np.pi * t / 2).round()).astype(np.float32))                 # single exact tone: bin n/4
+    x = np.stack(frames)
+    for excl in (False, True):
+        mref, pbref, pmref = O.rfft_mag_peak(x, "none", exclude_dc_nyq=excl)
+        gaps = O.top2_gap(mref[:6], excl)
+        assert (np.delete(gaps, 4) == 0).all() and (excl or gaps[4] == 0)            # the oracle itself sees exact ties
+        mag, pb_a, pm_a = fft_amd.rfft_peak(x, "none", exclude_dc_nyq=excl)
+        _, pb_b, pm_b = fft_amd.rfft_peak(x, "none", write_mag=False, exclude_dc_nyq=excl)
+        np.testing.assert_array_equal(pb_a, pbref)
+        np.testing.assert_array_equal(pb_b, pbref)
+        np.testing.assert_array_equal(pm_a, pmref.astype(np.float32))
+        np.testing.assert_array_equal(pm_b, pm_a)
+        np.testing.assert_array_equal(mag, mref.astype(np.float32))
+    # the same frames through the device-resident entry point in a batch large enough for the one-shot workgroups
+    reps = 700
+    xb = np.tile(x, (reps, 1))
+    _, pbref, _ = O.rfft_mag_peak(x, "none")
+    for wm in (True, False):
+        _, pb, _ = fft_amd.rfft_peak(xb, "none", write_mag=wm)
+        np.testing.assert_array_equal(pb, np.tile(pbref, reps))

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+import _escapes
 from oracle import spectrum_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -32,9 +33,11 @@ def check(pcm, nfft, hop, win):
     rel = np.linalg.norm(mag - mref, axis=-1) / np.maximum(np.linalg.norm(mref, axis=-1), 1e-30)
     assert rel.max() < 1e-5 * np.log2(nfft)
     bad = np.nonzero(pb != pbref)
+    _escapes.compared(pb.size)
     if len(bad[0]):
         gap = O.top2_gap(mref[bad])
         assert (gap < 1e-5).all()
+        _escapes.note("test_gpu_stft.check", len(bad[0]), f"nfft {nfft} hop {hop} gaps {gap[:8]}")
     np.testing.assert_allclose(pm, pmref, rtol=2e-4)
 
 
