@@ -42,6 +42,10 @@ struct StftArgs {
     float* peak_mag;        // [2][nframes]
 };
 
+}  // namespace sa
+#include "stft8192.h"      // nfft = 8192: 32 points per thread, two exchanges (uses StftArgs)
+namespace sa {
+
 // frames per workgroup: small transforms share a workgroup of >= 256 threads
 template <int LR, int PP> constexpr int stft_fpw() {
     constexpr int tpf = FftPlan<LR, PP>::TPF;
@@ -317,6 +321,22 @@ static int launch_stereo_pp(const StftArgs& a, hipStream_t st) {
     return SA_OK;
 }
 
+template <class M, int TEAMS>
+static int launch_stft8192(const StftArgs& a, hipStream_t st) {
+    static thread_local uint64_t attr_devs = 0;
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(stft8192_kernel<M, TEAMS>), Stft32::LDS_BYTES * TEAMS, &attr_devs));
+    const int64_t cap = (grid_cap(64 / TEAMS, "STFT") + 7) / 8 * 8, need = ((a.nframes + TEAMS - 1) / TEAMS + 7) / 8 * 8;
+    hipLaunchKernelGGL((stft8192_kernel<M, TEAMS>), dim3((unsigned)(need < cap ? need : cap)), dim3(Stft32::T * TEAMS), Stft32::LDS_BYTES * TEAMS, st, a);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+// SA_STFT_V (A/B aid) for nfft 8192: 0 = the 16-point-per-thread kernel with the folded radix-2 tail (round 2),
+// 1 = 32 points per thread, plain fp32 arithmetic, 2 = the same with packed fp32 arithmetic (default)
+static int stft_version() {
+    static const int v = getenv("SA_STFT_V") ? atoi(getenv("SA_STFT_V")) : 1;
+    return v;
+}
+
 // SA_STFT_PP (tuning aid): points per thread of the stereo kernel (8 or 16)
 static int stft_pp_override() {
     static const int v = getenv("SA_STFT_PP") ? atoi(getenv("SA_STFT_PP")) : 0;
@@ -369,7 +389,11 @@ int stft_pcm16_dev(const int16_t* pcm, int64_t n_samples, int32_t channels, int3
             case 10: return launch_stereo<10>(a, st);
             case 11: return launch_stereo<11>(a, st);
             case 12: return launch_stereo<12>(a, st);
-            case 13: return launch_stereo<13>(a, st);
+            case 13:
+                if (stft_version() == 3) return launch_stft8192<MathPlain, 2>(a, st);   // two lock-stepped teams per workgroup
+                if (stft_version() == 2) return launch_stft8192<MathPk, 1>(a, st);
+                if (stft_version() == 1) return launch_stft8192<MathPlain, 1>(a, st);
+                return launch_stereo<13>(a, st);
         }
     }
     // generic channel count: de-interleave + convert, then strided batched rfft
