@@ -4,6 +4,7 @@
 
 #include "rfft_generic.h"
 #include "rfft4096.h"
+#include "rfft_f64_32768.h"
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -165,6 +166,23 @@ int dispatch_generic<double>(int log2n, const RfftArgs<double>& a, hipStream_t s
     return SA_EUNSUP;
 }
 
+// fp64 n = 32768: one kernel, two 8192-point halves through LDS (rfft_f64_32768.h).  SA_F64_32768=0 (A/B aid) sends the
+// size through the multi-pass path as before.
+static bool f64_32768_single_pass() {
+    static const bool v = getenv("SA_F64_32768") ? atoi(getenv("SA_F64_32768")) != 0 : true;
+    return v;
+}
+static int launch_f64_32768(const RfftArgs<double>& a, hipStream_t st) {
+    constexpr int lds = rf64b_lds_bytes();
+    static_assert(lds <= 160 * 1024, "half transform does not fit LDS");
+    static thread_local uint64_t attr_devs = 0;
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(rfft_f64_32768_kernel), lds, &attr_devs));
+    const int64_t cap = grid_cap(32, "GENERIC");
+    hipLaunchKernelGGL(rfft_f64_32768_kernel, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(RF64B_T), lds, st, a);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
 static int ilog2_exact(int64_t n) {
     if (n <= 0 || (n & (n - 1))) return -1;
     int l = 0;
@@ -197,8 +215,12 @@ int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32
     int log2n = 0;
     SA_TRY(check_args(x, batch, n, window, flags, mag, peak_bin, peak_mag, &log2n));
     if (batch == 0) return SA_OK;
-    // frames longer than one LDS-resident pass: the multi-pass path (rfft_large.hip; packed or overlapping frames)
-    if (log2n > (sizeof(T) == 8 ? 14 : 15))
+    // frames longer than one LDS-resident pass: the multi-pass path (rfft_large.hip; packed or overlapping frames) —
+    // except fp64 frames of 32768 points on even sample boundaries, which one kernel handles as two LDS-resident halves
+    const int64_t stride_ = frame_stride > 0 ? frame_stride : n;
+    const bool f64_15 = sizeof(T) == 8 && log2n == 15 && f64_32768_single_pass() && (stride_ % 2) == 0 &&
+                        (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T))) == 0;
+    if (log2n > (sizeof(T) == 8 ? 14 : 15) && !f64_15)
         return rfft_large_dev<T>(x, batch, frame_stride, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
     const RfftPlan* p = get_rfft_plan(sizeof(T) == 8, n, window, win_param);
     if (!p) return SA_EHIP;
@@ -211,6 +233,9 @@ int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32
     a.db_floor = sizeof(T) == 8 ? (T)SA_DB_FLOOR_F64 : (T)SA_DB_FLOOR_F32;
     a.win_sym = p->win_sym;
     a.unaligned = (a.frame_stride % 2) != 0 || (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T))) != 0;
+    if constexpr (sizeof(T) == 8) {
+        if (f64_15) return launch_f64_32768(a, st);
+    }
     return dispatch_generic<T>(log2n, a, st);
 }
 

@@ -1,0 +1,189 @@
+// rfft_f64_32768.h — fused  window -> real FFT -> |Y| (-> dB) -> argmax  for fp64 frames of 32768 points in ONE kernel.
+//
+// Replaces per frame np.abs(fft(y*w)) and np.argmax (reference main.py:475, 479, 1029, 1627) at the one fp64 size that
+// used to fall through to the multi-pass path (rfft_large.hip: 22 bytes moved per 12 algorithmic, 1.9 TB/s).
+//
+// The packed sequence z[c] = x[2c] + i x[2c+1] has M = 16384 complex fp64 points = 256 KiB: twice what a workgroup's LDS
+// holds.  One decimation-in-frequency radix-2 step in registers splits it,
+//     u[n] = z[n] + z[n + 8192],      v[n] = (z[n] - z[n + 8192]) w_16384^n,      n < 8192,
+// into the even bins Z[2m] = FFT_8192(u)[m] and the odd bins Z[2m+1] = FFT_8192(v)[m].  A 512-thread workgroup reads
+// the frame ONCE (32 points per thread), runs the 8192-point LDS transform (lds_fft.h, 16 points per thread: the
+// four-pass plan 16 * 2 * 16 * 16 of the fp64 n = 16384 kernel) on u while v waits in 64 registers, then on v.  (First
+// version: 1024 threads x 8 points, five passes per half: 2.27 TB/s of algorithmic bytes against 1.98 multi-pass.)
+// The Hermitian pairs (Z[k], Z[M - k]) join bins of the same parity, so each half
+// is post-processed on its own: even half -> bins 2m and M - 2m, kept in 32 registers; odd half -> bins 2m + 1 and
+// M - 2m - 1, written together with the kept ones as runs of adjacent bins.  HBM traffic = the frame once + the
+// spectrum once.
+#pragma once
+#include "lds_fft.h"
+#include "rfft_generic.h"
+
+namespace sa {
+
+// w_8192^i read out of the w_16384 table (every other entry)
+struct TwHalfOf16384 {
+    const double2* __restrict__ tw;      // w_16384^i, i < 16384
+    template <int J, int HPREV, int MJ> __device__ __forceinline__ double2 get(int id) const { return tw[2 * HPREV * (id % MJ)]; }
+};
+
+constexpr int RF64B_LR = 13, RF64B_P = 16, RF64B_T = 512;
+constexpr int rf64b_lds_bytes() { return lds_fft_elems<double, RF64B_LR>() * 16 + 16 * (8 + 4) + 16; }
+
+__global__ void __launch_bounds__(RF64B_T) rfft_f64_32768_kernel(RfftArgs<double> a) {
+    using T = double;
+    using C = double2;
+    constexpr int LR = RF64B_LR, P = RF64B_P, TPF = RF64B_T;
+    constexpr int H = 1 << LR;               // 8192: points per half transform
+    constexpr int M = 2 * H;                 // 16384 packed points; bins 0..M
+    constexpr int S = LdsPadShift<T>::value;
+    constexpr int NIT = (H / 2) / TPF;       // 4 pairs per thread and half
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    C* buf = reinterpret_cast<C*>(smem_raw);
+    T* red_mag = reinterpret_cast<T*>(buf + lds_fft_elems<T, LR>());
+    int* red_bin = reinterpret_cast<int*>(red_mag + 16);
+    const int tl = threadIdx.x;
+    const TwHalfOf16384 tw{a.twM};
+    const C wt = a.twM[tl];                  // w_16384^tl: launch constant of the thread
+    const bool excl = (a.flags & 4) != 0, wdb = (a.flags & 2) != 0;
+
+    for (int64_t frame = blockIdx.x; frame < a.batch; frame += gridDim.x) {
+        int tq = tl;                          // opaque per frame
+        asm volatile("" : "+v"(tq));
+        tq &= TPF - 1;
+        const C* xf = reinterpret_cast<const C*>(a.x + frame * a.frame_stride);
+        const C* wf = reinterpret_cast<const C*>(a.win);
+        C u[P], v[P];
+        // ---- one read of the frame: z[n], z[n + H] for n = 512 n1 + tq; window; radix-2 split --------------------------
+        // (requesting the lower half of the NEXT frame during the odd half's transform was tried: 85 spilled registers at the
+        // 256 budget, 1.38 -> 1.44 ms per 2^28 samples)
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+            u[n1] = xf[n1 * TPF + tq];
+            v[n1] = xf[H + n1 * TPF + tq];
+        }
+        if (a.win) {
+            // the window in batches of 8 table loads (all 32 in flight beside the frame would need 128 more registers)
+#pragma unroll
+            for (int b = 0; b < P / 4; ++b) {
+                C wl[4], wh[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { wl[j] = wf[(4 * b + j) * TPF + tq]; wh[j] = wf[H + (4 * b + j) * TPF + tq]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u[4 * b + j].x *= wl[j].x; u[4 * b + j].y *= wl[j].y;
+                    v[4 * b + j].x *= wh[j].x; v[4 * b + j].y *= wh[j].y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+            // w_16384^(512 n1 + tq) = w_32^n1 w_16384^tq;  w_32^e = cos(2 pi e / 32) - i sin(2 pi e / 32)
+            constexpr T q[9] = {(T)1, (T)0.98078528040323044912618223613424, (T)0.92387953251128675612818318939679,
+                                (T)0.83146961230254523707878837761791, (T)0.70710678118654752440084436210485,
+                                (T)0.55557023301960222474283081394853, (T)0.38268343236508977172845998403040,
+                                (T)0.19509032201612826784828486847702, (T)0};
+#pragma unroll
+            for (int n1 = 0; n1 < P; ++n1) {
+                const C s = cadd(u[n1], v[n1]), d = csub(u[n1], v[n1]);
+                u[n1] = s;
+                const C dw = cmul(d, wt);
+                const T c = n1 <= 8 ? q[n1] : -q[16 - n1], sn = n1 <= 8 ? q[8 - n1] : q[n1 - 8];
+                v[n1] = n1 == 0 ? dw : n1 == 8 ? mul_mi(dw) : cmul(dw, mk<T>(c, -sn));
+            }
+        }
+        const bool wmag = (a.flags & 1) != 0 && a.mag != nullptr;
+        T* mf = a.mag + frame * (int64_t)(M + 1);
+        T best = (T)-1;
+        int best_k = 0x7fffffff;
+        T me_lo[NIT], me_hi[NIT], m_mid = 0;     // |X| of the even half: bins 2m, M - 2m (and bin M/2 on thread 0)
+
+        // one Hermitian pair: (zq, zm) = (Z[k], Z[M - k]), wq = w_N^k  ->  |X[k]|, |X[M - k]|
+        auto pair = [&](C zq, C zm, C wq, bool dc, T& ma, T& mb) {
+            const C e0 = mk<T>((T)0.5 * (zq.x + zm.x), (T)0.5 * (zq.y - zm.y));
+            const C d = mk<T>((T)0.5 * (zq.x - zm.x), (T)0.5 * (zq.y + zm.y));
+            C wo = cmul(mk<T>(d.y, -d.x), wq);
+            C e = e0;
+            // k = 0: X[0] = Re Z0 + Im Z0, X[M] = Re Z0 - Im Z0 exactly (keeps +-inf where the general form gives NaN,
+            // rfft_generic.h)
+            e.y = dc ? (T)0 : e.y;
+            wo.x = dc ? d.y : wo.x;
+            wo.y = dc ? (T)0 : wo.y;
+            const C xa = cadd(e, wo), xb = csub(e, wo);
+            ma = mag_sqrt(xa.x * xa.x + xa.y * xa.y);
+            mb = mag_sqrt(xb.x * xb.x + xb.y * xb.y);
+        };
+        auto track = [&](T m, int k) {
+            const bool g = !(excl && (k == 0 || k == M)) && peak_better(m, k, best, best_k);
+            best = g ? m : best; best_k = g ? k : best_k;
+        };
+
+        // ---- even half: U = FFT(u) -> bins 2m and M - 2m ---------------------------------------------------------------------
+        lds_fft_tw<T, LR, P, false>(u, buf, tl, tw);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int m = tq + TPF * i;
+            const C wq = a.twM[m];                                              // w_N^(2m) = w_16384^m
+            const C zq = buf[lds_pad<S>(m)];
+            const C zm = buf[lds_pad<S>((H - m) & (H - 1))];                    // m = 0 pairs with itself
+            pair(zq, zm, wq, m == 0, me_lo[i], me_hi[i]);
+            track(me_lo[i], 2 * m);
+            track(me_hi[i], M - 2 * m);
+        }
+        if (tq == 0) {                                                          // bin M/2: X = conj(Z[M/2]) = conj(U[H/2])
+            const C z = buf[lds_pad<S>(H / 2)];
+            m_mid = mag_sqrt(z.x * z.x + z.y * z.y);
+            track(m_mid, M / 2);
+        }
+        __syncthreads();                                                        // every thread has read U: the buffer is free
+        // ---- odd half: V = FFT(v) -> bins 2m + 1 and M - 2m - 1 --------------------------------------------------------------
+        lds_fft_tw<T, LR, P, false>(v, buf, tl, tw);
+        __syncthreads();
+        auto finish = [&](auto DBT) {
+            constexpr bool DB = decltype(DBT)::value;
+            auto out = [&](T m) { return DB ? (T)20 * log10(fmax(m, a.db_floor)) : m; };
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int m = tq + TPF * i;
+                const C wq = a.twN[2 * m + 1];                                  // w_N^(2m+1)
+                const C zq = buf[lds_pad<S>(m)];
+                const C zm = buf[lds_pad<S>(H - 1 - m)];
+                T mo_lo, mo_hi;
+                pair(zq, zm, wq, false, mo_lo, mo_hi);
+                track(mo_lo, 2 * m + 1);
+                track(mo_hi, M - 2 * m - 1);
+                if (wmag) {
+                    mf[2 * m] = out(me_lo[i]);
+                    mf[2 * m + 1] = out(mo_lo);
+                    mf[M - 2 * m - 1] = out(mo_hi);
+                    mf[M - 2 * m] = out(me_hi[i]);
+                }
+            }
+            if (tq == 0 && wmag) mf[M / 2] = out(m_mid);
+        };
+        if (wdb) finish(std::true_type{}); else finish(std::false_type{});
+        // ---- peak over the workgroup ---------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const T om = __shfl_xor(best, off);
+            const int ok = __shfl_xor(best_k, off);
+            const bool tk = peak_better(om, ok, best, best_k);
+            best = tk ? om : best; best_k = tk ? ok : best_k;
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red_mag[wave] = best; red_bin[wave] = best_k; }
+        __syncthreads();
+        if (tl == 0) {
+            for (int w = 1; w < TPF / 64; ++w) {
+                const T om = red_mag[w];
+                const int ok = red_bin[w];
+                if (peak_better(om, ok, best, best_k)) { best = om; best_k = ok; }
+            }
+            a.peak_bin[frame] = best_k;
+            a.peak_mag[frame] = best;
+        }
+        __syncthreads();                                                        // buf and red_* are reused by the next frame
+    }
+}
+
+}  // namespace sa

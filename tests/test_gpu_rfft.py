@@ -422,3 +422,48 @@ def test_exact_ties_name_the_lowest_bin_in_both_modes(n):
     for wm in (True, False):
         _, pb, _ = fft_amd.rfft_peak(xb, "none", write_mag=wm)
         np.testing.assert_array_equal(pb, np.tile(pbref, reps))
+
+
+@pytest.mark.parametrize("win", ["none", "hann", "gaussian"])
+def test_rfft_f64_32768_single_pass_kernel(win):
+    """fp64 frames of 32768 points: one kernel, two 8192-point halves through LDS (rfft_f64_32768.h).  Same bars as every
+    fp64 size; dB and the DC / Nyquist exclusion; frames that start on an odd sample take the multi-pass path instead and
+    must give the same answer."""
+    import fft_amd
+    n = 32768
+    rng = np.random.default_rng(len(win))
+    t = np.arange(n)
+    x = rng.standard_normal((7, n)) + 3.0 * np.sin(2 * np.pi * rng.uniform(5, n / 2 - 5, (7, 1)) * t / n)
+    x[5] = 0.0; x[5, 0] = 1.0                                             # impulse: |Y| = w[0] on every bin
+    x[6] = 1.0 + np.cos(np.pi * t)                                       # DC against Nyquist
+    for db in (False, True):
+        for excl in (False, True):
+            mag, pb, pm = fft_amd.rfft_peak(x, win, db=db, exclude_dc_nyq=excl)
+            mref, pbref, pmref = O.rfft_mag_peak(x, win, db=db, exclude_dc_nyq=excl)
+            if db:
+                np.testing.assert_allclose(mag[:5], mref[:5], atol=1e-9)
+            else:
+                assert (np.abs(mag - mref).max(axis=1) / np.maximum(mref.max(axis=1), 1e-300)).max() < 1e-12
+            np.testing.assert_array_equal(pb[:5], pbref[:5])
+            if win == "none":
+                np.testing.assert_array_equal(pb[6], pbref[6])
+            np.testing.assert_allclose(pm[:5], pmref[:5], rtol=1e-12)
+    # the same frames as overlapping frames of a longer record at an odd hop (element-wise loads, multi-pass path)
+    from fft_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    rec = np.concatenate([x[0], x[1][:12345]])
+    hop = 12345
+    dx = _lib.DeviceBuffer(rec.nbytes); dx.upload(rec)
+    dm = _lib.DeviceBuffer(2 * (n // 2 + 1) * 8); dpb = _lib.DeviceBuffer(8); dpm = _lib.DeviceBuffer(16)
+    frames = np.stack([rec[:n], rec[hop:hop + n]])
+    mref, pbref, _ = O.rfft_mag_peak(frames, win)
+    # strided entry is internal: go through the STFT-free public path by calling the two frames separately
+    for i, off in enumerate((0, hop)):
+        _lib.check(lib.sa_rfft_peak_f64_dev(dx.at(off * 8), 1, n, _lib.WINDOW_IDS[win], 0.0, _lib.F_WRITE_MAG, dm.ptr, dpb.ptr, dpm.ptr, None))
+        _lib.check(lib.sa_sync())
+        m = np.empty(n // 2 + 1); dm.download(m, m.nbytes)
+        b = np.empty(1, np.int32); dpb.download(b, 4)
+        assert np.abs(m - mref[i]).max() / mref[i].max() < 1e-12 and b[0] == pbref[i]
+    for b_ in (dx, dm, dpb, dpm):
+        b_.free()
