@@ -290,6 +290,9 @@ static int run_strided(int lr, const C2cArgs& a, hipStream_t st) {
     const int far = a.batch * a.A * (a.S / 8) >= 8 * (int64_t)num_cus() ? far_env : 0;
     if (c2c_stream_nt(a)) {
         if (lr == 10 && (far & 1)) return launch_strided<10, 8, true, true>(a, st);
+        // SA_C2C_B16 (A/B aid, profiles/r03_c5_split_ab.txt): radix-512 passes take 16 columns per workgroup (256-byte segments)
+        static const int b16 = getenv("SA_C2C_B16") ? atoi(getenv("SA_C2C_B16")) : 0;
+        if (lr == 9 && (far & 2) && b16 && a.S % 16 == 0) return launch_strided<9, 16, true, true>(a, st);
         if (lr == 9 && (far & 2)) return launch_strided<9, 8, true, true>(a, st);
     }
     if (lr == 10 && (far & 1)) return launch_strided<10, 8, true>(a, st);
@@ -331,6 +334,7 @@ static int run_final_multi(int lr, const C2cArgs& a, hipStream_t st) {
     if (c2c_stream_nt(a)) {
         if (lr == 10 && (pp16 & 1)) return launch_final<10, 8, 16, true>(a, st);
         if (lr == 9) return launch_final<9, 8, C2C_PP, true>(a, st);
+        if (lr == 11) return launch_final<11, 4, 16, true>(a, st);        // 2048-point rows (SA_C2C_SPLIT experiments only)
     }
     if (lr == 10 && (pp16 & 1) && a.batch * (a.A / 8) >= 8 * (int64_t)num_cus()) return launch_final<10, 8, 16>(a, st);
     switch (lr) {
@@ -396,6 +400,12 @@ int c2c_f64_dev(const double* in, double* out, double* work, int64_t n, int64_t 
     int l1, l2, l3 = 0;
     if (L <= 20) { l1 = (L + 1) / 2; l2 = L - l1; }
     else { l1 = (L + 2) / 3; l2 = (L - l1 + 1) / 2; l3 = L - l1 - l2; }
+    // SA_C2C_SPLIT="l1,l2,l3" (A/B aid): another factorisation of a three-pass transform, e.g. 9,10,11 at 2^30
+    if (l3 && getenv("SA_C2C_SPLIT")) {
+        int e1 = 0, e2 = 0, e3 = 0;
+        if (sscanf(getenv("SA_C2C_SPLIT"), "%d,%d,%d", &e1, &e2, &e3) == 3 && e1 + e2 + e3 == L && e1 >= 6 && e1 <= 10 && e2 >= 6 && e2 <= 10 &&
+            e3 >= 6 && e3 <= 11 && (e3 < 11 || c2c_stream_nt(a))) { l1 = e1; l2 = e2; l3 = e3; }
+    }
     const int64_t R1 = 1LL << l1, R2 = 1LL << l2, R3 = 1LL << l3;
     // pass 1: [1][R1][n/R1], in -> work
     a.in = reinterpret_cast<const Cd*>(in); a.out = reinterpret_cast<Cd*>(work);
