@@ -78,6 +78,8 @@ PROTOTYPES = {
     "sa_spectral_metrics_f64": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp]),
     "sa_spectral_metrics_f32_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),
     "sa_spectral_metrics_f64_dev": (C.c_int, [_vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),
+    "sa_v15_readouts_f64": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "sa_v15_readouts_f64_dev": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
     "sa_cubic_upsample_f64": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "sa_cubic_upsample_f64_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "sa_analyze_frames_f32": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp]),
@@ -131,6 +133,12 @@ class SpecMetrics(C.Structure):
     _fields_ = [("fund_amp", _dbl), ("harmonic_power", _dbl), ("max_spur", _dbl), ("noise_power", _dbl),
                 ("total_power", _dbl), ("sideband_amp", _dbl), ("fund_bin", _i32), ("harm_lo_bin", _i32),
                 ("n_peaks", _i32), ("top_peak_bin", _i32), ("bw_lo_bin", _i32), ("bw_hi_bin", _i32)]
+
+
+class V15Readouts(C.Structure):
+    """struct sa_v15_readouts (include/specengine.h)."""
+    _fields_ = [("max", _dbl), ("median", _dbl), ("sideband_max", _dbl), ("y_max", _dbl), ("argmax", _i64), ("bw_first", _i64),
+                ("bw_last", _i64), ("sideband_count", _i64), ("above_half_max", _i64), ("nan_count", _i64)]
 
 
 def _share_hip_runtime_with_torch():

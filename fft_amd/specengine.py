@@ -273,6 +273,22 @@ def time_stats(y):
     return out[0] if y.ndim == 1 else out
 
 
+def v15_readouts(Y, f=None, y=None):
+    """sa_v15_readouts_f64 for one record: the reductions of versão15.py's panel over the full shifted spectrum Y (with
+    its frequency axis f) and the time samples y.  Returns the ctypes struct (include/specengine.h: sa_v15_readouts)."""
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    if Y.ndim != 1 or len(Y) < 1:
+        raise ValueError("Y must be a non-empty one-dimensional array")
+    f = None if f is None else np.ascontiguousarray(f, dtype=np.float64)
+    y = None if y is None else np.ascontiguousarray(y, dtype=np.float64)
+    if f is not None and len(f) != len(Y):
+        raise ValueError("f and Y must have the same length")
+    out = _lib.V15Readouts()
+    import ctypes as C
+    _lib.check(_lib.load().sa_v15_readouts_f64(_lib.ptr(y), 0 if y is None else len(y), _lib.ptr(f), _lib.ptr(Y), len(Y), 1, C.byref(out)))
+    return out
+
+
 def find_peaks(x, height=None, distance=None, height_rel=None):
     """scipy.signal.find_peaks(x, height=, distance=)[0] on the device (sa_find_peaks_f64), as the reference
     calls it (main.py:1034, 1639).  `height_rel` takes the threshold as a fraction of max(x)."""
@@ -481,11 +497,16 @@ def analysis_panels_v15(last_data, waveform, am_on=False, fm_on=False):
     Differences from main.py's panel: the fundamental is np.argmax over the FULL shifted spectrum (:1101, the negative
     twin), find_peaks(height = 5 % of max, distance = 10) runs over the full spectrum (:1108), SNR comes from the median
     (:1126-1131), the bandwidth from `Y > A/sqrt 2` over the full array, the duty cycle from `y > max/2`.
-    Device: time statistics of y and of Y (sa_time_stats_f64), find_peaks (sa_find_peaks_f64); the few scalar read-outs
-    on top (median, first/last index above the half-power level) are taken on the host from arrays it already holds."""
+    Device: time statistics of y and of Y (sa_time_stats_f64), find_peaks (sa_find_peaks_f64), and — round 3 — every
+    remaining reduction over an array (sa_v15_readouts_f64: argmax, median by exact radix select, first / last index above
+    the half-power level, side-band maximum under the reference's frequency mask, the duty-cycle count).  The host only
+    picks single elements out of arrays it already holds and formats strings."""
     y = np.asarray(last_data["y"])
     t, f, Y = np.asarray(last_data["t"]), np.asarray(last_data["f"]), np.asarray(last_data["Y"])
     tp, fp = {}, {}
+    Y64 = np.ascontiguousarray(Y, dtype=np.float64)
+    # one device call for every array reduction of the panel (last_data's arrays have equal lengths, main.py:479)
+    r = v15_readouts(Y64, f, y if len(y) > 0 else None) if len(Y) > 0 else None
     if len(y) > 0:
         s = time_stats(np.ascontiguousarray(y, dtype=np.float64))
         n = len(y)
@@ -496,7 +517,8 @@ def analysis_panels_v15(last_data, waveform, am_on=False, fm_on=False):
         tp["zero_crossing"] = f"{rate:.2f} Hz"
         tp["frequency"] = f"{freq:.2f} Hz" if freq is not None else "---"
         if waveform.startswith("Quadrada") or waveform.startswith("Pulso"):
-            tp["duty_cycle"] = f"{np.sum(y > (s.max * 0.5)) / n * 100:.1f}%"          # threshold max/2, not the mid level (:1081)
+            above = r.above_half_max if r is not None else v15_readouts(y, None, y).above_half_max
+            tp["duty_cycle"] = f"{above / n * 100:.1f}%"                               # threshold max/2, not the mid level (:1081)
         else:
             tp["duty_cycle"] = "N/A"
         tp["peak_to_rms"] = f"{crest:.4f}"
@@ -504,9 +526,8 @@ def analysis_panels_v15(last_data, waveform, am_on=False, fm_on=False):
             tp["kurtosis"] = f"{np.float64(s.m4) / np.float64(s.m2) ** 2 - 3.0:.4f}"
             tp["skewness"] = f"{np.float64(s.m3) / np.float64(s.m2) ** 1.5:.4f}"
     if len(Y) > 0:
-        Y64 = np.ascontiguousarray(Y, dtype=np.float64)
         sY = time_stats(Y64)
-        i0 = int(sY.argmax)                                                          # np.argmax(Y): first maximum (:1101)
+        i0 = int(r.argmax)                                                           # np.argmax(Y): first maximum (:1101)
         f0, A = f[i0], Y[i0]
         fp["fundamental"], fp["fund_amp"] = format_freq(f0), f"{A:.4f}"
         peaks = find_peaks(Y64, height=sY.max * 0.05, distance=10)
@@ -516,21 +537,19 @@ def analysis_panels_v15(last_data, waveform, am_on=False, fm_on=False):
             fp["thd"], fp["harmonics"] = f"{np.sqrt(hpow / A ** 2) * 100:.2f}%", f"{hpow / A ** 2:.4f}"
         else:
             fp["thd"], fp["harmonics"] = "0%", "0"
-        noise_floor = np.median(Y)
+        noise_floor = Y.dtype.type(r.median)                # np.median(Y) in Y's own type (float32 on the import path)
         if noise_floor > 0:
             fp["snr"] = f"{10 * np.log10(sY.mean_sq * len(Y) / (noise_floor ** 2 * len(Y))):.2f} dB"
             fp["noise_floor"] = f"{noise_floor:.4f}"
         else:
             fp["snr"], fp["noise_floor"] = "∞ dB", "---"
         fp["sfdr"] = f"{20 * np.log10(A / np.max(Y[hp[1:]])):.2f} dB" if len(hp) > 1 else "∞ dB"
-        bw = np.where(Y > A / np.sqrt(2))[0]
-        fp["bandwidth"] = format_freq(f[bw[-1]] - f[bw[0]]) if len(bw) > 0 else "---"
+        fp["bandwidth"] = format_freq(f[r.bw_last] - f[r.bw_first]) if r.bw_first >= 0 else "---"
         if am_on:
             with np.errstate(all="ignore"):
                 fp["mod_index"] = f"{(s.max - s.min) / (s.max + s.min) * 100:.1f}%"
         elif fm_on:
-            sb = np.where((f > f0 * 0.5) & (f < f0 * 1.5) & (f != f0))[0]
-            fp["mod_index"] = f"{np.max(Y[sb]) / A * 100:.1f}%" if len(sb) > 0 else "---"
+            fp["mod_index"] = f"{Y.dtype.type(r.sideband_max) / A * 100:.1f}%" if r.sideband_count > 0 else "---"
         else:
             fp["mod_index"] = "N/A"
         fp["peak_freq"] = format_freq(f[hp[1]]) if len(hp) > 1 else "---"

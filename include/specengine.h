@@ -388,6 +388,23 @@ int sa_spectral_metrics_f32_dev(const float* mag, int64_t batch, int64_t n, doub
 int sa_spectral_metrics_f64_dev(const double* mag, int64_t batch, int64_t n, double freq_step, double side_hz,
                                 sa_spec_metrics* out, void* stream);
 
+/* ---- the second call-site's panel (versão15.py:1038-1180): read-outs its formulas take over the FULL fftshift-ordered
+ *      spectrum Y [batch][n] with the shared frequency axis f [n], and over the time samples y [batch][ny] -------------------
+ *   argmax, max          np.argmax(Y) (first maximum, the negative-frequency twin; the first NaN if there is one), Y[argmax] (:1101)
+ *   median               np.median(Y) (:1127; NaN when Y holds a NaN) — exact order statistics, mean of the two middle ones
+ *   bw_first, bw_last    np.where(Y > max / np.sqrt(2))[0][[0, -1]] (:1145-1148), -1 when empty
+ *   sideband_max, _count np.max(Y[(f > 0.5 f0) & (f < 1.5 f0) & (f != f0)]), f0 = f[argmax] (:1163-1166); count 0 = empty mask
+ *   above_half_max, y_max  np.sum(y > np.max(y) * 0.5), np.max(y) (:1081; -1 / 0 when y is NULL)
+ * y and f may be NULL (their read-outs are then skipped).  fp64; integers exact, doubles are elements of the input. */
+typedef struct sa_v15_readouts {
+    double  max, median, sideband_max, y_max;
+    int64_t argmax, bw_first, bw_last, sideband_count, above_half_max, nan_count /* 1 when Y holds a NaN */;
+} sa_v15_readouts;
+int sa_v15_readouts_f64(const double* y, int64_t ny, const double* f, const double* Y, int64_t n, int64_t batch,
+                        sa_v15_readouts* out /*[batch]*/);
+int sa_v15_readouts_f64_dev(const double* y, int64_t ny, const double* f, const double* Y, int64_t n, int64_t batch,
+                            sa_v15_readouts* out, void* stream);
+
 /* ---- whole read-out of a batch of records: what one "Calcular" does after synthesis (calculate_fft,
  *      main.py:977-987 -> _calculate_time_analysis :989-1024 / update_analysis_panels :1542-1735), per frame --
  * x [batch][n] -> window -> rfft -> |Y| on the device, then sa_time_stats over the frame and

@@ -92,3 +92,48 @@ def test_v15_import_wav_float32_path(golden_dir):
         tp, fp = S.analysis_panels_v15(d, c["waveform"], c["am"], c["fm"])
         _check_panels(tp, c["panel_time"], 1e-5, c)
         _check_panels(fp, c["panel_freq"], 1e-4, c)
+
+
+def _ref_readouts(y, f, Y):
+    """numpy, statement by statement as versão15.py:1081, 1101, 1127, 1145-1148, 1163-1166"""
+    i0 = int(np.argmax(Y))
+    A, f0 = Y[i0], f[i0]
+    bw = np.where(Y > A / np.sqrt(2))[0]
+    sb = np.where((f > f0 * 0.5) & (f < f0 * 1.5) & (f != f0))[0]
+    with np.errstate(all="ignore"):
+        return {"argmax": i0, "max": A, "median": np.median(Y), "bw_first": int(bw[0]) if len(bw) else -1,
+                "bw_last": int(bw[-1]) if len(bw) else -1, "sideband_count": len(sb),
+                "sideband_max": np.max(Y[sb]) if len(sb) else None, "above_half_max": int(np.sum(y > np.max(y) * 0.5))}
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 16, 1500, 2000, 4097, 100000])
+def test_v15_readouts_entry_point_matches_numpy(n):
+    """sa_v15_readouts_f64 against the reference's own numpy statements: random spectra, spectra full of duplicates (the
+    median's two middle order statistics fall inside a run of equal values), mirror-symmetric |FFT| rows whose argmax is
+    the negative-frequency twin (empty side-band mask), a NaN in the row."""
+    rng = np.random.default_rng(n)
+    fs = 48000.0
+    f = np.fft.fftshift(np.fft.fftfreq(n, 1 / fs))
+    rows = [np.abs(rng.standard_normal(n)), np.round(np.abs(rng.standard_normal(n)) * 3) / 3, np.full(n, 2.5),
+            np.abs(np.fft.fftshift(np.fft.fft(np.sin(2 * np.pi * 0.1 * np.arange(n)) + 0.01 * rng.standard_normal(n))))]
+    pos = rows[0].copy()
+    pos[(3 * n) // 4] = 50.0                                             # positive-frequency maximum: non-empty side band
+    rows.append(pos)
+    if n >= 3:
+        bad = rows[0].copy(); bad[n // 3] = np.nan
+        rows.append(bad)
+    for Y in rows:
+        y = rng.standard_normal(n) + 0.3
+        r = S.v15_readouts(Y, f, y)
+        ref = _ref_readouts(y, f, Y)
+        assert r.argmax == ref["argmax"] and (r.max == ref["max"] or (np.isnan(r.max) and np.isnan(ref["max"])))
+        assert r.median == ref["median"] or (np.isnan(r.median) and np.isnan(ref["median"]))
+        assert (r.bw_first, r.bw_last) == (ref["bw_first"], ref["bw_last"])
+        assert r.sideband_count == ref["sideband_count"]
+        if ref["sideband_max"] is not None:
+            assert r.sideband_max == ref["sideband_max"] or (np.isnan(r.sideband_max) and np.isnan(ref["sideband_max"]))
+        assert r.above_half_max == ref["above_half_max"]
+    # float32 spectra (the import path): the median comes back exactly as np.median's float32 value once rounded
+    Y32 = np.abs(rng.standard_normal(max(n, 2))).astype(np.float32)
+    f2 = np.fft.fftshift(np.fft.fftfreq(len(Y32), 1 / fs))
+    assert np.float32(S.v15_readouts(Y32, f2).median) == np.median(Y32)
