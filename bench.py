@@ -195,6 +195,13 @@ def main():
         tj = json.load(open(tfile))
         traffic = tj["traffic_bytes_per_launch"] * batch / tj["frames_per_launch"]
 
+    # N > 1: the frame-sharded paths' one exchange, natively (sa_comm_*: the library's own RCCL communicator; the id
+    # travels over the harness' process group) — every rank's peak records to rank 0, under a watchdog so that a stuck
+    # collective costs an `error` entry and not the line
+    native_gather = None
+    if dist is not None and not args.no_extra:
+        native_gather = native_gather_report(dist, rank, world, dpb, dpm, batch)
+
     if rank == 0:
         # sanity: a sample of frames vs the CPU oracle (not timed)
         from oracle import spectrum_oracle as O
@@ -238,6 +245,12 @@ def main():
                                            "achieved_GBps": achieved_b, "frac": achieved_b / HBM_PEAK_GBS,
                                            "alg_bytes_per_frame": ALG_BYTES_B}},
         }
+        if native_gather is not None:
+            gathered = native_gather.pop("_bins", None)
+            if native_gather.get("ok") and gathered is not None:
+                # rank 0's own shard leads the gathered records: its first frames must be the ones checked above
+                native_gather["own_shard_matches"] = bool((gathered[:nh] == pbs[:nh]).all()) and len(gathered) == batch * world
+            out["extra"]["native_gather"] = native_gather
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(xs if ns >= 2048 else _more_frames(dx, n))
     # the headline is measured: release its buffers before anything else runs on the GPUs
@@ -302,6 +315,36 @@ def extra_child_main(args):
     except Exception as e:                                      # noqa: BLE001
         res["error"] = f"{type(e).__name__}: {e}"
     print(json.dumps(res), flush=True)
+
+
+def native_gather_report(dist, rank, world, dpb, dpm, batch, timeout=90.0):
+    """fft_amd.dist.NativeComm.gather_peaks across the ranks of this run, in a watchdog thread."""
+    import threading
+    res = {"ok": False, "records": batch * world}
+
+    def work():
+        try:
+            from fft_amd.dist import NativeComm
+            box = [NativeComm.new_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            t0 = time.perf_counter()
+            with NativeComm(rank, world, ident=box[0]) as comm:
+                res["init_ms"] = (time.perf_counter() - t0) * 1e3
+                t1 = time.perf_counter()
+                bins, mags = comm.gather_peaks(dpb, dpm, batch * world)
+                res["gather_ms"] = (time.perf_counter() - t1) * 1e3
+            if rank == 0:
+                res["_bins"] = bins
+                res["finite"] = bool(np.isfinite(mags).all())
+            res["ok"] = True
+        except Exception as e:                                  # noqa: BLE001
+            res["error"] = f"{type(e).__name__}: {e}"
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        res["error"] = f"no result within {timeout:.0f} s (thread abandoned)"
+    return res
 
 
 def secondary_configs(lib, args):

@@ -40,6 +40,10 @@ PROTOTYPES = {
     "sa_thread_state_count": (C.c_int, []),
     "sa_shard_devices": (C.c_int, [_vp, _i32]),
     "sa_shard_count": (C.c_int, []),
+    "sa_comm_unique_id": (C.c_int, [_vp]),
+    "sa_comm_create": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32]),
+    "sa_comm_destroy": (C.c_int, [_vp]),
+    "sa_comm_gather_peaks_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "sa_rfft_peak_f32": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "sa_rfft_peak_f64": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "sa_rfft_peak_f32_dev": (C.c_int, [_vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp]),
@@ -90,6 +94,7 @@ PROTOTYPES = {
 
 
 DIST_MAX_RANKS = 16
+COMM_ID_BYTES = 128
 DIST_NATURAL_IN, DIST_NATURAL_OUT = 1, 2
 DIST_XCHG_AUTO, DIST_XCHG_DMA, DIST_XCHG_KERNEL, DIST_XCHG_FUSED, DIST_XCHG_RCCL = 0, 1, 2, 3, 4
 DIST_XCHG_NAMES = {"auto": 0, "dma": 1, "kernel": 2, "fused": 3, "rccl": 4}

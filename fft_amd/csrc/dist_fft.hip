@@ -28,7 +28,7 @@
 #include <dlfcn.h>
 #include <string.h>
 
-#include <rccl/rccl.h>       // types and prototypes only; the entry points are resolved with dlsym
+#include "rccl_api.h"
 
 #include <vector>
 
@@ -42,40 +42,6 @@ int dist_phase2(const double* in_blocked, double* work, double* out, int64_t S, 
                 int nt, hipStream_t st);
 
 using Cd = double2;
-
-struct RcclApi {
-    void* lib = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclAllToAll) AllToAll = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    bool ok = false;
-};
-static const RcclApi* rccl_api() {
-    static const RcclApi api = [] {
-        RcclApi a;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (a.lib) break;
-        }
-        if (!a.lib) return a;
-        a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(a.lib, "ncclCommInitAll"));
-        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
-        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
-        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
-        a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(a.lib, "ncclSend"));
-        a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(a.lib, "ncclRecv"));
-        a.AllToAll = reinterpret_cast<decltype(a.AllToAll)>(dlsym(a.lib, "ncclAllToAll"));
-        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
-        a.ok = a.CommInitAll && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.AllToAll && a.GetErrorString;
-        return a;
-    }();
-    return api.ok ? &api : nullptr;
-}
 
 // dst[r * dpitch + c] = src[r * spitch + c]  (16-byte elements; rows are long, so a flat grid-stride loop coalesces)
 __global__ void __launch_bounds__(256) dist_copy2d_kernel(Cd* __restrict__ dst, int64_t dpitch, const Cd* __restrict__ src,

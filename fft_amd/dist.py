@@ -17,8 +17,14 @@ Two sharding patterns, as SURVEY §8(e):
    Result: rank q owns rows k1 of X[k1 + R1*k'] ("transposed" order, [R1/P][S]).  Natural-order slabs on either side
    cost one more all-to-all each (flags).
 
-torch appears only in `gather_peaks` (result gather of the frame-sharded paths, 8 bytes per frame).
+The result gather of the frame-sharded paths (8 bytes per frame) is native since round 3: `NativeComm` (sa_comm_*:
+grouped ncclSend / ncclRecv on a communicator the library owns, the id handed round through a file).  `gather_peaks`
+below is the same gather over torch.distributed — kept for the CPU (gloo) tests of the partition helpers and for
+harnesses that already hold a process group; no product path needs torch.
 """
+import os
+import time
+
 import numpy as np
 
 
@@ -30,7 +36,8 @@ def shard_range(total, rank, world):
 
 
 def gather_peaks(peak_bin, peak_mag, group=None, dst=0):
-    """Gather per-shard peak records to `dst` (8 bytes per frame). Returns (bins, mags) on dst, else (None, None).
+    """The gather of NativeComm.gather_peaks over torch.distributed (CPU / gloo tests, harnesses with a process group of
+    their own): per-shard peak records to `dst` (8 bytes per frame).  Returns (bins, mags) on dst, else (None, None).
     Shards may have different lengths (shard_range): lengths are exchanged first."""
     import torch
     import torch.distributed as dist
@@ -52,6 +59,95 @@ def gather_peaks(peak_bin, peak_mag, group=None, dst=0):
     bins = torch.cat([o[:s, 0] for o, s in zip(out, sizes)]).to(torch.int32)
     mags = torch.cat([o[:s, 1] for o, s in zip(out, sizes)])
     return bins, mags
+
+
+def exchange_comm_id(path, rank, payload=None, timeout=120.0):
+    """Hand rank 0's `payload` (the SA_COMM_ID_BYTES of sa_comm_unique_id) to every rank through the file `path`:
+    rank 0 writes it (temporary name + rename, so a reader never sees a partial file), the others wait for it.
+    Returns the payload.  The launcher's own channel (an environment variable, a store) works just as well."""
+    if rank == 0:
+        if payload is None:
+            raise ValueError("rank 0 provides the payload")
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(payload)
+        os.replace(tmp, path)
+        return bytes(payload)
+    t0 = time.monotonic()
+    while True:
+        try:
+            with open(path, "rb") as fh:
+                data = fh.read()
+            if data:
+                return data
+        except FileNotFoundError:
+            pass
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError(f"no communicator id at {path} after {timeout:.0f} s")
+        time.sleep(0.01)
+
+
+class NativeComm:
+    """One process per GPU: this rank's RCCL communicator, owned by libspecengine (sa_comm_*; no torch).
+    id_path: file through which rank 0 publishes the communicator id (default: SA_COMM_ID_FILE, else a name derived
+    from the launcher's MASTER_PORT under /tmp).  The calling process' current device is the rank's device."""
+
+    @staticmethod
+    def new_id():
+        """A fresh communicator id (rank 0 calls this and hands the bytes to the other ranks)."""
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+        _lib.check(_lib.load().sa_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, rank, world, id_path=None, timeout=120.0, ident=None):
+        """ident: the id bytes when the caller has moved them itself (any channel the launcher offers); otherwise they go
+        through the file id_path."""
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C, self.lib = _lib, C, _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        if ident is None:
+            path = id_path or os.environ.get("SA_COMM_ID_FILE") or f"/tmp/sa_comm_id_{os.environ.get('MASTER_PORT', 'local')}"
+            ident = exchange_comm_id(path, self.rank, NativeComm.new_id() if self.rank == 0 else None, timeout)
+        if len(ident) != _lib.COMM_ID_BYTES:
+            raise RuntimeError(f"communicator id file {path} holds {len(ident)} bytes, expected {_lib.COMM_ID_BYTES}")
+        self._h = C.c_void_p()
+        _lib.check(self.lib.sa_comm_create(C.byref(self._h), ident, self.rank, self.world))
+
+    def gather_peaks(self, peak_bin, peak_mag, total, root=0):
+        """peak_bin / peak_mag: this rank's device buffers (fft_amd._lib.DeviceBuffer or a raw pointer) holding the
+        records of its shard_range(total, rank, world) frames.  Returns (bins int32[total], mags float32[total]) as
+        numpy arrays on `root`, (None, None) elsewhere."""
+        _lib, C = self._lib, self._C
+        counts = [shard_range(total, r, self.world) for r in range(self.world)]
+        counts = (C.c_int64 * self.world)(*[hi - lo for lo, hi in counts])
+        ptr = lambda b: b.ptr if hasattr(b, "ptr") else C.c_void_p(int(b))      # noqa: E731
+        ab = am = None
+        if self.rank == root and total > 0:
+            ab, am = _lib.DeviceBuffer(total * 4), _lib.DeviceBuffer(total * 4)
+        _lib.check(self.lib.sa_comm_gather_peaks_dev(self._h, ptr(peak_bin), ptr(peak_mag), counts[self.rank], counts, int(root),
+                                                     ab.ptr if ab else None, am.ptr if am else None, None))
+        _lib.check(self.lib.sa_sync())
+        if self.rank != root:
+            return None, None
+        bins, mags = np.empty(total, np.int32), np.empty(total, np.float32)
+        if total > 0:
+            ab.download(bins); am.download(mags)
+            ab.free(); am.free()
+        return bins, mags
+
+    def close(self):
+        if self._h:
+            self.lib.sa_comm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def stft_shard(n_samples, nfft, hop, rank, world):

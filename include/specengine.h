@@ -101,6 +101,22 @@ int  sa_thread_state_count(void);
 int sa_shard_devices(const int32_t* devices, int32_t count);
 int sa_shard_count(void);
 
+/* Process-per-GPU form of the frame-sharded paths (one process per device, e.g. under torchrun): the ONLY
+ * exchange is the gather of the per-frame peak records (8 bytes per frame) to one rank, natively over RCCL — the
+ * reference is one process (main.py:448), this has no counterpart there.  Rank 0 calls sa_comm_unique_id and passes the
+ * SA_COMM_ID_BYTES bytes to the other ranks (fft_amd/dist.py: through a file); every rank calls sa_comm_create with its
+ * device current.  sa_comm_gather_peaks_dev: rank r contributes counts[r] records (counts: host array [world], the same
+ * on every rank — fft_amd.dist.shard_range gives it without an exchange); `root` receives them in rank order into
+ * all_bins / all_mags (device memory, sum(counts) entries; ignored elsewhere).  Enqueued on `stream`, not synchronised.
+ * SA_EUNSUP when librccl.so cannot be loaded. */
+#define SA_COMM_ID_BYTES 128
+typedef struct sa_comm sa_comm;
+int sa_comm_unique_id(void* id /* SA_COMM_ID_BYTES bytes */);
+int sa_comm_create(sa_comm** comm, const void* id, int32_t rank, int32_t world);
+int sa_comm_destroy(sa_comm* comm);
+int sa_comm_gather_peaks_dev(sa_comm* comm, const int32_t* peak_bin, const float* peak_mag, int64_t count, const int64_t* counts,
+                             int32_t root, int32_t* all_bins, float* all_mags, void* stream);
+
 /* ---- a6/a8/a9/a11: window -> real FFT -> |Y| (-> dB) -> dominant peak, batched ----------------
  * Replaces, per frame:  Y = fft(y*w); np.abs(Y); np.argmax(...)   (main.py:475, 479, 1029, 1627)
  * computed as an rfft: bins 0..n/2 (the reference's length-n fftshift layout is rebuilt by the

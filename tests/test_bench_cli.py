@@ -73,6 +73,10 @@ def test_two_ranks_on_one_gpu_report_the_distributed_fft():
     assert "one device per rank" in dist[("rccl", 1)]["error"]
     fan = j["extra"]["shard_fan_out"]
     assert fan.get("bit_identical_peaks") is True, fan
+    # the native gather ran its control flow on both ranks; two ranks on one device is something RCCL refuses, so here it
+    # reports an error instead of records (on an N-GPU node it reports ok + own_shard_matches)
+    ng = j["extra"]["native_gather"]
+    assert ng["records"] == 2 << 14 and (ng.get("ok") or "error" in ng), ng
 
 
 @pytest.mark.gpu

@@ -77,3 +77,24 @@ def test_dist_layout_helpers_roundtrip():
         X = D.natural_from_rows(rows, R1, S)
         ref = np.fft.fft(x)
         assert np.abs(X - ref).max() / np.abs(ref).max() < 1e-12
+
+
+def test_comm_id_file_rendezvous(tmp_path):
+    """The id of the native communicator (fft_amd.dist.NativeComm) travels from rank 0 to the others through a file: late
+    readers wait for it, nobody sees a partial file."""
+    import threading
+    from fft_amd import dist as D
+    path = str(tmp_path / "id")
+    got = {}
+
+    def reader(r):
+        got[r] = D.exchange_comm_id(path, r, timeout=10)
+    th = [threading.Thread(target=reader, args=(r,)) for r in (1, 2, 3)]
+    [t.start() for t in th]
+    payload = bytes(range(128))
+    assert D.exchange_comm_id(path, 0, payload) == payload
+    [t.join() for t in th]
+    assert all(got[r] == payload for r in (1, 2, 3))
+    import pytest
+    with pytest.raises(TimeoutError):
+        D.exchange_comm_id(str(tmp_path / "never"), 1, timeout=0.05)

@@ -180,3 +180,26 @@ def test_dist_argument_errors():
     bad = (C.c_int32 * 2)(0, 99)
     assert lib.sa_dist_plan_create(C.byref(h), 1 << 20, 2, bad, 0) == _lib.SA_EINVAL
     assert lib.sa_dist_execute(None, None) == _lib.SA_EINVAL
+
+
+def test_native_gather_of_peak_records_one_rank(tmp_path):
+    """The process-per-GPU gather (sa_comm_*: grouped ncclSend / ncclRecv on a communicator owned by the library) with the
+    one rank a one-GPU box allows: the records go through RCCL's send-to-self path and come back in order."""
+    import numpy as np
+    from fft_amd import _lib
+    from fft_amd import dist as D
+    n = 1000
+    rng = np.random.default_rng(0)
+    pb = rng.integers(0, 2049, n).astype(np.int32)
+    pm = rng.random(n).astype(np.float32)
+    dpb, dpm = _lib.DeviceBuffer(n * 4), _lib.DeviceBuffer(n * 4)
+    dpb.upload(pb); dpm.upload(pm)
+    with D.NativeComm(0, 1, id_path=str(tmp_path / "id")) as comm:
+        bins, mags = comm.gather_peaks(dpb, dpm, n)
+        np.testing.assert_array_equal(bins, pb)
+        np.testing.assert_array_equal(mags, pm)
+        b0, m0 = comm.gather_peaks(dpb, dpm, 0)
+        assert len(b0) == 0 and len(m0) == 0
+    lib = _lib.load()
+    assert lib.sa_comm_create(None, None, 0, 1) == _lib.SA_EINVAL
+    dpb.free(); dpm.free()
