@@ -4,7 +4,7 @@
 
 #include "rfft_generic.h"
 #include "rfft4096.h"
-#include "rfft_f64_32768.h"
+#include "rfft_split2.h"
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -166,19 +166,20 @@ int dispatch_generic<double>(int log2n, const RfftArgs<double>& a, hipStream_t s
     return SA_EUNSUP;
 }
 
-// fp64 n = 32768: one kernel, two 8192-point halves through LDS (rfft_f64_32768.h).  SA_F64_32768=0 (A/B aid) sends the
-// size through the multi-pass path as before.
-static bool f64_32768_single_pass() {
-    static const bool v = getenv("SA_F64_32768") ? atoi(getenv("SA_F64_32768")) != 0 : true;
+// fp64 n = 32768 / fp32 n = 65536: one kernel, two LDS-resident halves (rfft_split2.h).  SA_SPLIT2=0 (A/B aid) sends
+// these sizes through the multi-pass path as before.
+static bool split2_single_kernel() {
+    static const bool v = getenv("SA_SPLIT2") ? atoi(getenv("SA_SPLIT2")) != 0 : true;
     return v;
 }
-static int launch_f64_32768(const RfftArgs<double>& a, hipStream_t st) {
-    constexpr int lds = rf64b_lds_bytes();
+template <typename T> static int launch_split2(const RfftArgs<T>& a, hipStream_t st) {
+    constexpr int LR = sizeof(T) == 8 ? 13 : 14;
+    constexpr int lds = rsplit2_lds_bytes<T, LR>();
     static_assert(lds <= 160 * 1024, "half transform does not fit LDS");
     static thread_local uint64_t attr_devs = 0;
-    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(rfft_f64_32768_kernel), lds, &attr_devs));
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(rfft_split2_kernel<T, LR>), lds, &attr_devs));
     const int64_t cap = grid_cap(32, "GENERIC");
-    hipLaunchKernelGGL(rfft_f64_32768_kernel, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(RF64B_T), lds, st, a);
+    hipLaunchKernelGGL((rfft_split2_kernel<T, LR>), dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3((1 << LR) / 16), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
@@ -216,9 +217,10 @@ int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32
     SA_TRY(check_args(x, batch, n, window, flags, mag, peak_bin, peak_mag, &log2n));
     if (batch == 0) return SA_OK;
     // frames longer than one LDS-resident pass: the multi-pass path (rfft_large.hip; packed or overlapping frames) —
-    // except fp64 frames of 32768 points on even sample boundaries, which one kernel handles as two LDS-resident halves
+    // except the first size beyond it (fp64 32768, fp32 65536) on even sample boundaries, which one kernel handles as two
+    // LDS-resident halves
     const int64_t stride_ = frame_stride > 0 ? frame_stride : n;
-    const bool f64_15 = sizeof(T) == 8 && log2n == 15 && f64_32768_single_pass() && (stride_ % 2) == 0 &&
+    const bool f64_15 = log2n == (sizeof(T) == 8 ? 15 : 16) && split2_single_kernel() && (stride_ % 2) == 0 &&
                         (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T))) == 0;
     if (log2n > (sizeof(T) == 8 ? 14 : 15) && !f64_15)
         return rfft_large_dev<T>(x, batch, frame_stride, n, window, win_param, flags, mag, peak_bin, peak_mag, st);
@@ -233,9 +235,7 @@ int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32
     a.db_floor = sizeof(T) == 8 ? (T)SA_DB_FLOOR_F64 : (T)SA_DB_FLOOR_F32;
     a.win_sym = p->win_sym;
     a.unaligned = (a.frame_stride % 2) != 0 || (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T))) != 0;
-    if constexpr (sizeof(T) == 8) {
-        if (f64_15) return launch_f64_32768(a, st);
-    }
+    if (f64_15) return launch_split2<T>(a, st);
     return dispatch_generic<T>(log2n, a, st);
 }
 

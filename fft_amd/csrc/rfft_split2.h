@@ -1,9 +1,11 @@
-// rfft_f64_32768.h — fused  window -> real FFT -> |Y| (-> dB) -> argmax  for fp64 frames of 32768 points in ONE kernel.
+// rfft_split2.h — fused  window -> real FFT -> |Y| (-> dB) -> argmax  in ONE kernel for the frame length that is TWICE
+// what a workgroup's LDS holds: fp64 frames of 32768 points and fp32 frames of 65536 points.
 //
-// Replaces per frame np.abs(fft(y*w)) and np.argmax (reference main.py:475, 479, 1029, 1627) at the one fp64 size that
-// used to fall through to the multi-pass path (rfft_large.hip: 22 bytes moved per 12 algorithmic, 1.9 TB/s).
+// Replaces per frame np.abs(fft(y*w)) and np.argmax (reference main.py:475, 479, 1029, 1627) at the sizes that used to
+// fall through to the multi-pass path (rfft_large.hip: 14 / 22 bytes moved per 6 / 12 algorithmic, 1.8 - 1.9 TB/s).
 //
-// The packed sequence z[c] = x[2c] + i x[2c+1] has M = 16384 complex fp64 points = 256 KiB: twice what a workgroup's LDS
+// Written out for fp64 n = 32768 (fp32 n = 65536: 32768 packed points, halves of 16384, 1024 threads, w_32768):
+// the packed sequence z[c] = x[2c] + i x[2c+1] has M = 16384 complex fp64 points = 256 KiB: twice what a workgroup's LDS
 // holds.  One decimation-in-frequency radix-2 step in registers splits it,
 //     u[n] = z[n] + z[n + 8192],      v[n] = (z[n] - z[n + 8192]) w_16384^n,      n < 8192,
 // into the even bins Z[2m] = FFT_8192(u)[m] and the odd bins Z[2m+1] = FFT_8192(v)[m].  A 512-thread workgroup reads
@@ -20,19 +22,20 @@
 
 namespace sa {
 
-// w_8192^i read out of the w_16384 table (every other entry)
-struct TwHalfOf16384 {
-    const double2* __restrict__ tw;      // w_16384^i, i < 16384
-    template <int J, int HPREV, int MJ> __device__ __forceinline__ double2 get(int id) const { return tw[2 * HPREV * (id % MJ)]; }
+// w_H^i read out of the w_2H table (every other entry)
+template <typename T> struct TwEveryOther {
+    const cplx<T>* __restrict__ tw;      // w_2H^i, i < 2H
+    template <int J, int HPREV, int MJ> __device__ __forceinline__ cplx<T> get(int id) const { return tw[2 * HPREV * (id % MJ)]; }
 };
 
-constexpr int RF64B_LR = 13, RF64B_P = 16, RF64B_T = 512;
-constexpr int rf64b_lds_bytes() { return lds_fft_elems<double, RF64B_LR>() * 16 + 16 * (8 + 4) + 16; }
+template <typename T, int LR> constexpr int rsplit2_lds_bytes() { return lds_fft_elems<T, LR>() * (int)sizeof(cplx<T>) + 16 * (8 + 4) + 16; }
 
-__global__ void __launch_bounds__(RF64B_T) rfft_f64_32768_kernel(RfftArgs<double> a) {
-    using T = double;
-    using C = double2;
-    constexpr int LR = RF64B_LR, P = RF64B_P, TPF = RF64B_T;
+// LR: log2 of the half transform; 16 points per thread and half.  fp64: LR = 13 (512 threads), fp32: LR = 14 (1024 threads).
+template <typename T, int LR>
+__global__ void __launch_bounds__((1 << LR) / 16) rfft_split2_kernel(RfftArgs<T> a) {
+    using C = cplx<T>;
+    constexpr int P = 16, TPF = (1 << LR) / P;
+    static_assert(2 * (1 << LR) / TPF == 32, "the split's factors are w_32^n1 times a per-thread factor");
     constexpr int H = 1 << LR;               // 8192: points per half transform
     constexpr int M = 2 * H;                 // 16384 packed points; bins 0..M
     constexpr int S = LdsPadShift<T>::value;
@@ -42,7 +45,7 @@ __global__ void __launch_bounds__(RF64B_T) rfft_f64_32768_kernel(RfftArgs<double
     T* red_mag = reinterpret_cast<T*>(buf + lds_fft_elems<T, LR>());
     int* red_bin = reinterpret_cast<int*>(red_mag + 16);
     const int tl = threadIdx.x;
-    const TwHalfOf16384 tw{a.twM};
+    const TwEveryOther<T> tw{a.twM};
     const C wt = a.twM[tl];                  // w_16384^tl: launch constant of the thread
     const bool excl = (a.flags & 4) != 0, wdb = (a.flags & 2) != 0;
 
@@ -163,6 +166,7 @@ __global__ void __launch_bounds__(RF64B_T) rfft_f64_32768_kernel(RfftArgs<double
         };
         if (wdb) finish(std::true_type{}); else finish(std::false_type{});
         // ---- peak over the workgroup ---------------------------------------------------------------------------------------------
+        if (best != best) best = (T)-1;          // (never: peak_better admits no NaN)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const T om = __shfl_xor(best, off);

@@ -110,7 +110,7 @@ def test_rfft_long_frames_dev_entry_on_every_kind_of_stream():
     import torch
     from fft_amd import _lib
     lib = _lib.load()
-    n, batch = 1 << 16, 700                       # several 64 MiB chunks
+    n, batch = 1 << 17, 350                       # several 64 MiB chunks (2^16 is one kernel since round 3: rfft_split2.h)
     x = torch.randn(batch, n, device="cuda")
     outs = []
     side = torch.cuda.Stream()
@@ -425,8 +425,35 @@ def test_exact_ties_name_the_lowest_bin_in_both_modes(n):
 
 
 @pytest.mark.parametrize("win", ["none", "hann", "gaussian"])
+def test_rfft_f32_65536_split_kernel(win):
+    """fp32 frames of 65536 points: one kernel, two 16384-point halves through LDS (rfft_split2.h), against the oracle at the
+    fp32 bar; dB, the DC / Nyquist exclusion, exact known answers (impulse, DC against Nyquist)."""
+    import fft_amd
+    n = 65536
+    rng = np.random.default_rng(len(win) + 7)
+    t = np.arange(n)
+    x = (rng.standard_normal((6, n)) + 3.0 * np.sin(2 * np.pi * rng.uniform(5, n / 2 - 5, (6, 1)) * t / n)).astype(np.float32)
+    x[4] = 0.0; x[4, 0] = 1.0
+    x[5] = (1.0 + np.cos(np.pi * t)).astype(np.float32)
+    for db in (False, True):
+        for excl in (False, True):
+            mag, pb, pm = fft_amd.rfft_peak(x, win, db=db, exclude_dc_nyq=excl)
+            mref, pbref, pmref = O.rfft_mag_peak(x, win, db=db, exclude_dc_nyq=excl)
+            if db:
+                np.testing.assert_allclose(mag[:4], mref[:4], atol=2e-2)           # dB of near-zero bins amplifies fp32 rounding
+            else:
+                assert rel_l2(mag[:4], mref[:4]).max() < 1e-5 * 16
+                if win == "none":
+                    np.testing.assert_array_equal(mag[4:], mref[4:].astype(np.float32))   # exact cases
+            check_peaks(pb[:4], pm[:4], mref[:4], pbref[:4], excl)
+            if win == "none":
+                np.testing.assert_array_equal(pb[4:], pbref[4:])
+            np.testing.assert_allclose(pm[:4], pmref[:4], rtol=1e-4)
+
+
+@pytest.mark.parametrize("win", ["none", "hann", "gaussian"])
 def test_rfft_f64_32768_single_pass_kernel(win):
-    """fp64 frames of 32768 points: one kernel, two 8192-point halves through LDS (rfft_f64_32768.h).  Same bars as every
+    """fp64 frames of 32768 points: one kernel, two 8192-point halves through LDS (rfft_split2.h).  Same bars as every
     fp64 size; dB and the DC / Nyquist exclusion; frames that start on an odd sample take the multi-pass path instead and
     must give the same answer."""
     import fft_amd
