@@ -4,6 +4,7 @@
 
 #include "rfft_generic.h"
 #include "rfft4096.h"
+#include "rfft4096_pair.h"
 #include "rfft_split2.h"
 #include <condition_variable>
 #include <mutex>
@@ -80,9 +81,33 @@ static bool r4k_nt() {
     return v;
 }
 
+// Two waves per frame (rfft4096_pair.h), one-shot workgroups of F frames.
+template <int MODE, int F>
+static int launch_r4k_pair(const RfftArgs<float>& a, hipStream_t st) {
+    auto kern = rfft4096_pair_kernel<MODE, F, R4K_NT_STREAM>;
+    constexpr int lds = r4p_lds_bytes(F);
+    static thread_local uint64_t attr_devs = 0;
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs));
+    const int64_t need = (a.batch + F - 1) / F;
+    if (need > 0x7fffffff) { set_error("rfft4096: batch too large for one launch"); return SA_EUNSUP; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)need), dim3(F * 128), lds, st, a.x, a.batch, a.frame_stride, a.win, a.twM, a.twN,
+                       (a.flags & SA_F_EXCLUDE_DC_NYQ) ? 1 : 0, a.mag, a.peak_bin, a.peak_mag, a.db_floor);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
 template <int MODE>
 static int launch_r4k(const RfftArgs<float>& a, hipStream_t st) {
     if (r4k_variant() == 1) return launch_r4k_v<MODE, 12, true>(a, st);
+    // SA_R4K_PAIR = frames per workgroup of the two-waves-per-frame kernel (2, 3 or 4), 0 = one wave per frame
+    static const int pair = getenv("SA_R4K_PAIR") ? atoi(getenv("SA_R4K_PAIR")) : 0;
+    if constexpr (MODE != 0) {
+        if (pair && a.win_sym && r4k_nt()) {
+            if (pair == 2) return launch_r4k_pair<MODE, 2>(a, st);
+            if (pair == 3) return launch_r4k_pair<MODE, 3>(a, st);
+            if (pair == 4) return launch_r4k_pair<MODE, 4>(a, st);
+        }
+    }
     // Spectra written, symmetric window: one-shot 3-wave workgroups on the half window table (rfft4096.h, VAR = 3),
     // four to a CU (36.5 KiB of LDS each) — their set-up, load latency and drain overlap each other's arithmetic.
     // Measured at 2^20 / 2^18 frames (M spectra/s; profiles/r01_wg_shape_ab.txt, same box per line group):
