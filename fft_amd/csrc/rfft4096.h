@@ -201,8 +201,9 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
 #endif
                      ) {
 #ifdef R4K_DIAG
-    unsigned long long diag_acc[R4K_NSTAMP] = {0}, diag_prev = 0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(diag_prev)::"memory");
+    unsigned long long diag_acc[R4K_NSTAMP] = {0}, diag_prev = 0, diag_t0, diag_r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(diag_prev), "=s"(diag_r0)::"memory");
+    diag_t0 = diag_prev;
 #endif
     static_assert(!(MODE == 2 && (FUSE & 2)), "spectral metrics need the linear spectrum in the slab");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -470,6 +471,12 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
 #ifdef R4K_DIAG
     if (lane == 0)
         for (int i = 0; i < R4K_NSTAMP; ++i) atomicAdd(&diag_out[i], diag_acc[i]);
+    if (blockIdx.x == 3 && threadIdx.x == 0) {          // shader clock over this wave's life: s_memtime ticks per 100 MHz tick
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+        diag_out[R4K_NSTAMP] = t1 - diag_t0;
+        diag_out[R4K_NSTAMP + 1] = r1 - diag_r0;
+    }
 #endif
 }
 

@@ -11,14 +11,22 @@ n, batch = 4096, 1 << int(os.environ.get("LOG2B", "20"))
 dx = _lib.DeviceBuffer(batch * n * 4); dm = _lib.DeviceBuffer(batch * (n // 2 + 1) * 4)
 dpb = _lib.DeviceBuffer(batch * 4); dpm = _lib.DeviceBuffer(batch * 4)
 _lib.check(lib.sa_fill_tone_noise_f32_dev(dx.ptr, batch, n, 100e3, 0x5EED0002, None)); _lib.check(lib.sa_sync())
+MODEB = os.environ.get("MODEB", "0") == "1"           # peak only: no spectrum written
 res = {"env": {k: v for k, v in os.environ.items() if k.startswith("SA_")}}
 ms = C.c_float(0)
 out = []
 for _ in range(int(os.environ.get("ROUNDS", "3"))):
-    _lib.check(lib.sa_time_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, _lib.F_WRITE_MAG, dm.ptr, dpb.ptr, dpm.ptr, 20, C.byref(ms)))
+    _lib.check(lib.sa_time_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, 0 if MODEB else _lib.F_WRITE_MAG, None if MODEB else dm.ptr, dpb.ptr, dpm.ptr, 20, C.byref(ms)))
     out.append(ms.value)
-res["ms"] = out; res["ms_min"] = min(out); res["Mspectra_s"] = batch / min(out) / 1e3; res["GBps"] = 24588 * batch / min(out) / 1e6
-if os.environ.get("CHECK", "1") == "1":
+res["ms"] = out; res["ms_min"] = min(out); res["Mspectra_s"] = batch / min(out) / 1e3; res["GBps"] = (16392 if MODEB else 24588) * batch / min(out) / 1e6
+if MODEB and os.environ.get("CHECK", "1") == "1":
+    # every frame's peak against the spectrum-writing mode's (same arithmetic up to the root: bins of equal |Y| whose
+    # squares differ may be named differently, see rfft4096.h) and a sample against the oracle
+    pb = np.empty(batch, np.int32); dpb.download(pb); pm = np.empty(batch, np.float32); dpm.download(pm)
+    _lib.check(lib.sa_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, _lib.F_WRITE_MAG, dm.ptr, dpb.ptr, dpm.ptr, None)); _lib.check(lib.sa_sync())
+    pa = np.empty(batch, np.int32); dpb.download(pa); pma = np.empty(batch, np.float32); dpm.download(pma)
+    res["vs_mode_a_bin_mismatches"] = int((pa != pb).sum()); res["vs_mode_a_mag_mismatches"] = int((pma != pm).sum())
+elif os.environ.get("CHECK", "1") == "1":
     nb = n // 2 + 1
     pb = np.empty(batch, np.int32); dpb.download(pb); pm = np.empty(batch, np.float32); dpm.download(pm)
     bad = 0

@@ -4,6 +4,7 @@
 #include "../../fft_amd/csrc/rfft4096.h"
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 using namespace sa;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -16,20 +17,25 @@ int run(const char* name, float* dx, int64_t batch, float* dwin, float2* dtwM, f
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0;
-    for (int rep = 0; rep < 3; ++rep) {
-        CK(hipMemset(ddiag, 0, 8 * R4K_NSTAMP));
+    const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 3;
+    for (int rep = 0; rep < reps; ++rep) {
+        CK(hipMemset(ddiag, 0, 8 * (R4K_NSTAMP + 2)));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), lds, 0, dx, batch, (int64_t)4096, dwin, dtwM, dtwN, 0, dmag, dpb, dpm, 1e-30f, R4kFuse{}, ddiag);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
+        if (reps > 3 && (rep % 10 == 0 || rep == reps - 1)) {
+            unsigned long long c[2]; CK(hipMemcpy(c, ddiag + R4K_NSTAMP, 16, hipMemcpyDeviceToHost));
+            printf("   rep %3d: %.3f ms, clock %.0f MHz\n", rep, ms, c[0] / (c[1] / 100.0));
+        }
     }
-    unsigned long long h[R4K_NSTAMP];
+    unsigned long long h[R4K_NSTAMP + 2];
     CK(hipMemcpy(h, ddiag, sizeof(h), hipMemcpyDeviceToHost));
     double tot = 0; for (int i = 0; i < 9; ++i) tot += (double)h[i];
     printf("%-28s %.3f ms  cycles/frame/wave=%.0f  shares:", name, ms, tot / batch);
     const char* lbl[9] = {"loop", "load+win", "pass1", "x1a+p2a", "x1b+p2b", "x2a+p3a", "x2b+p3b", "herm+st", "peak"};
     for (int i = 0; i < 9; ++i) printf(" %s=%.1f%%", lbl[i], 100.0 * h[i] / tot);
-    printf("\n");
+    printf("  | one wave: %llu ticks in %.3f ms = %.0f MHz\n", h[R4K_NSTAMP], h[R4K_NSTAMP + 1] / 100e3, h[R4K_NSTAMP] / (h[R4K_NSTAMP + 1] / 100.0));
     return 0;
 }
 
@@ -37,7 +43,7 @@ int main() {
     const int64_t batch = 1 << 19;
     float *dx, *dwin, *dmag, *dpm; float2 *dtwM, *dtwN; int* dpb; unsigned long long* ddiag;
     CK(hipMalloc(&dx, batch * 4096 * 4)); CK(hipMalloc(&dmag, batch * 2049 * 4));
-    CK(hipMalloc(&dpb, batch * 4)); CK(hipMalloc(&dpm, batch * 4)); CK(hipMalloc(&ddiag, 8 * R4K_NSTAMP));
+    CK(hipMalloc(&dpb, batch * 4)); CK(hipMalloc(&dpm, batch * 4)); CK(hipMalloc(&ddiag, 8 * (R4K_NSTAMP + 2)));
     std::vector<float> hx(1 << 22);
     for (size_t i = 0; i < hx.size(); ++i) hx[i] = sinf(0.37f * i) + 0.1f * sinf(1.7f * i);
     for (int64_t o = 0; o < batch * 4096; o += (int64_t)hx.size()) CK(hipMemcpy(dx + o, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
