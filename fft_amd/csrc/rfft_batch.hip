@@ -14,7 +14,7 @@
 
 namespace sa {
 
-template <typename T, int LOG2M, int P>
+template <typename T, int LOG2M, int P, int VAR = 0>
 static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     constexpr int M = 1 << LOG2M;
     constexpr int TPF = M / P;
@@ -26,7 +26,7 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
                            (sizeof(T) == 4 && LOG2M == 13 && P == 16 && FPW == 1 ? FftTail2_8192::TAB * 8 : 0) +   // twiddle tables (rfft_generic.h: T2, T4)
                            (sizeof(T) == 4 && LOG2M == 14 && P == 16 && FPW == 1 ? FftTail4_16384::TAB * 8 : 0);
     static_assert(lds <= 160 * 1024, "frame does not fit LDS");
-    auto kern = rfft_mag_peak_generic<T, LOG2M, P, FPW>;
+    auto kern = rfft_mag_peak_generic<T, LOG2M, P, FPW, VAR>;
     static thread_local uint64_t attr_devs = 0;            // bit d: attribute set for device d (it is per device)
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_devs));
     const int64_t need = (a.batch + FPW - 1) / FPW;
@@ -166,7 +166,11 @@ int dispatch_generic<float>(int log2n, const RfftArgs<float>& a, hipStream_t st)
         case 12: return generic_p16(true) ? launch_generic<float, 11, 16>(a, st) : launch_generic<float, 11, 8>(a, st);
         case 13: return generic_p16(true) ? launch_generic<float, 12, 16>(a, st) : launch_generic<float, 12, 8>(a, st);
         case 14: return generic_p16(true) ? launch_generic<float, 13, 16>(a, st) : launch_generic<float, 13, 8>(a, st);
-        case 15: return launch_generic<float, 14, 16>(a, st);
+        case 15: {
+            // SA_GENERIC_PF (A/B aid): 1 = next-frame prefetch (rfft_generic.h VAR bit 0), 0 = window kept in registers
+            static const int pf = getenv("SA_GENERIC_PF") ? atoi(getenv("SA_GENERIC_PF")) : 0;
+            return pf && !a.unaligned ? launch_generic<float, 14, 16, 1>(a, st) : launch_generic<float, 14, 16>(a, st);
+        }
     }
     set_error("rfft f32: n=2^%d unsupported (16 <= n <= 32768, power of two)", log2n);
     return SA_EUNSUP;

@@ -38,7 +38,11 @@ template <typename T> struct RfftArgs {
     bool unaligned = false; // x + b * frame_stride is not a multiple of two elements for some b: load element-wise
 };
 
-template <typename T, int LOG2M, int P /*points per thread*/, int FPW /*frames per workgroup*/>
+// VAR bit 0 (PF): the NEXT frame's samples are requested as soon as the current frame's have entered the first pass and
+// stay in flight through the whole transform; the window is then re-read per frame (from L2) just before the post-pass
+// instead of being kept in registers.  For the sizes whose LDS buffer leaves ONE workgroup per CU, where nothing else
+// covers the frame's load time.
+template <typename T, int LOG2M, int P /*points per thread*/, int FPW /*frames per workgroup*/, int VAR = 0>
 // fp32, 16 points per thread, n = 8192 / 16384: just above 128 VGPRs unconstrained; capped there they run 4 waves
 // per SIMD (measured +4 % / +11 %; the smaller sizes measured slower capped)
 __global__ void __launch_bounds__((((1 << LOG2M) / P) * FPW), (sizeof(T) == 4 && P == 16 && LOG2M >= 12 && LOG2M <= 13 ? 4 : 1))
@@ -64,6 +68,9 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
     // Launch constants of a thread (same positions in every frame it handles): FFT twiddles always, window
     // samples and Hermitian factors too when they are cheap to keep (fp32); fp64 reloads them per frame.
     constexpr bool HOIST = sizeof(T) == 4;
+    constexpr bool PF = (VAR & 1) != 0;
+    constexpr bool HOISTW = HOIST && !PF;            // the thread's window samples stay in registers across frames
+    static_assert(!PF || HOIST, "the prefetching variant is written for fp32");
     constexpr int R0 = PL::radix(0);
     constexpr int NIT = (M / 2) / TPF;
     // fp32 n = 16384 (8192 complex points, 512 threads): the transform's last radix-2 pass is folded into the Hermitian
@@ -78,9 +85,9 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
     if constexpr (T2) tw2.load(reinterpret_cast<const float2*>(a.twM), tl, reinterpret_cast<float2*>(red_bin + NWAVES));
     else if constexpr (T4) tw4.load(reinterpret_cast<const float2*>(a.twM), tl, reinterpret_cast<float2*>(red_bin + NWAVES));
     else tw.load(a.twM, tl);
-    C w[HOIST ? P : 1];
+    C w[HOISTW ? P : 1];
     C tn[NTN];
-    if constexpr (HOIST) {
+    if constexpr (HOISTW) {
         if (a.win) {
 #pragma unroll
             for (int u = 0; u < P / R0; ++u)
@@ -94,9 +101,37 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
         // the 1/2 of the Hermitian split rides on the window (exact: a power of two)
 #pragma unroll
         for (int i = 0; i < P; ++i) { w[i].x *= (T)0.5; w[i].y *= (T)0.5; }
+    }
+    if constexpr (HOIST) {
 #pragma unroll
         for (int u = 0; u < NTN; ++u) tn[u] = a.twN[tl + TPF * u];
     }
+    // PF: samples of the next frame / window values for it, in the first pass' register order
+    C nx[PF ? P : 1], wn[PF ? P : 1];
+    // Buffer loads: the frame (or the window table) is the descriptor's base, the thread's position one 32-bit register,
+    // the 16 strides scalar offsets — no 64-bit address pair per load (they cost 32 registers in the pointer form).
+    // The launcher sends unaligned frames (odd STFT hops) to the non-prefetching instantiation.
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    auto load_cols = [&](const T* basep, C* dst, int tq) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(basep), 0, 2 * M * (int)sizeof(T), 0x00020000);
+#pragma unroll
+        for (int u = 0; u < P / R0; ++u)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; ++n1) {
+                const v2u_t d = __builtin_amdgcn_raw_buffer_load_b64(rs, tq * (int)sizeof(C), (n1 * (M / R0) + TPF * u) * (int)sizeof(C), 0);
+                dst[u * R0 + n1] = mk<T>(__uint_as_float(d[0]), __uint_as_float(d[1]));
+            }
+    };
+    auto load_x = [&](int64_t frame, C* dst, int tq) { load_cols(a.x + (frame < a.batch ? frame : 0) * a.frame_stride, dst, tq); };
+    auto load_w = [&](C* dst, int tq) {
+        if (a.win) {
+            load_cols(a.win, dst, tq);
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; ++i) dst[i] = mk<T>(1, 1);
+        }
+    };
+    if constexpr (PF) load_x((int64_t)blockIdx.x * FPW + g, nx, tl);
 
     for (int64_t base = (int64_t)blockIdx.x * FPW; base < a.batch; base += (int64_t)gridDim.x * FPW) {
         const int64_t frame = base + g;
@@ -110,7 +145,15 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
         // ---------------- global load (+window) into the first pass' registers, FFT through LDS -----
         // All loads of the frame are issued back to back (no per-element branch: frames past the end of
         // the batch re-read frame 0 and are discarded at the stores).
-        if (a.unaligned) {                               // frames may start on an odd sample (odd STFT hop): element loads
+        if constexpr (PF) {
+            // the window values come from L2 per frame (requested here, behind the prefetched samples: a short wait);
+            // keeping them across the post-pass beside the prefetch spilled 10 registers
+            load_w(wn, tq);
+            // (x w) / 2: the same bits as x (w / 2) of the hoisting form — halving is exact
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i] = mk<T>((nx[i].x * wn[i].x) * (T)0.5, (nx[i].y * wn[i].y) * (T)0.5);
+            load_x(base + (int64_t)gridDim.x * FPW + g, nx, tq);
+        } else if (a.unaligned) {                        // frames may start on an odd sample (odd STFT hop): element loads
 #pragma unroll
             for (int u = 0; u < P / R0; ++u)
 #pragma unroll
@@ -125,7 +168,8 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                 for (int n1 = 0; n1 < R0; ++n1)
                     v[u * R0 + n1] = reinterpret_cast<const C*>(xf)[n1 * (M / R0) + tq + TPF * u];
         }
-        if constexpr (HOIST) {
+        if constexpr (PF) {
+        } else if constexpr (HOIST) {
 #pragma unroll
             for (int i = 0; i < P; ++i) { v[i].x *= w[i].x; v[i].y *= w[i].y; }
         } else {
