@@ -32,7 +32,10 @@ static int launch_generic(const RfftArgs<T>& a, hipStream_t st) {
     const int64_t need = (a.batch + FPW - 1) / FPW;
     // more, shorter-lived workgroups than residency needs: fresh workgroups keep the waves out of step (see
     // launch_r4k_v); measured on 4096-point frames 174 -> 187 M spectra/s going from 8 to 32 per CU
-    const int64_t cap = grid_cap(32, "GENERIC");
+    // (fp32 n = 32768 is the exception: one 1024-thread workgroup fills a CU and its set-up — 128 KiB of window and
+    // twiddle tables into registers and LDS — is as large as a frame; 2 per CU instead of 32: 2.92 -> 3.31 TB/s at 8192
+    // frames, profiles/r03_generic_experiments.txt)
+    const int64_t cap = grid_cap(sizeof(T) == 4 && LOG2M == 14 ? 2 : 32, "GENERIC");
     const int grid = (int)(need < cap ? need : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, a);
     SA_HIP(hipGetLastError());
