@@ -7,13 +7,20 @@ from fft_amd import specengine as S
 from oracle import spectrum_oracle as O
 
 
-def peak_ok(pb, pbref, mref, site):
-    """exact, or — recorded — one of the oracle's top two when they are within 1e-4 of each other (fp32 pipeline)"""
+def peak_ok(pb, pbref, mref, site, what="", own=None):
+    """exact, or — recorded — one of the oracle's top two when they are within 1e-4 of each other (fp32 pipeline).
+    A gap below 1e-6 is no near miss but a tie by construction (the upsampled impulse: bins 0 and 1 differ by 5e-13 in
+    fp64, far below what fp32 arithmetic resolves): either bin is right, and the kernel must then name the first maximum of
+    ITS OWN spectrum — checked here instead of leaning on the hatch."""
     _escapes.compared(1)
     if pb == pbref:
         return True
-    if O.top2_gap(mref[None])[0] < 1e-4:
-        _escapes.note("test_gpu_pipeline." + site, 1)
+    gap = O.top2_gap(mref[None])[0]
+    if gap < 1e-6 and own is not None:
+        top2 = np.argsort(mref)[-2:]
+        return int(pb) in top2 and int(pb) == int(np.argmax(own))
+    if gap < 1e-4:
+        _escapes.note("test_gpu_pipeline." + site, 1, f"{what}: bin {int(pb)} vs oracle {int(pbref)}, oracle top-2 gap {gap:.3g}")
         return True
     return False
 
@@ -100,7 +107,7 @@ def test_pipeline_every_waveform_both_generator_classes_in_one_batch():
                                                        "Dente de Serra Modificado", "Passo (step)", "Tangente") and not p["fm_on"] else 0), (p["waveform"], int(bad.sum()))
         if not bad.any():
             assert np.linalg.norm(mag[i] - mref) / np.linalg.norm(mref) < 1e-5 * 14, p["waveform"]
-            assert peak_ok(pb[i], pbref, mref, "every_waveform"), p["waveform"]
+            assert peak_ok(pb[i], pbref, mref, "every_waveform", p["waveform"], own=mag[i]), p["waveform"]
     # noise and the overflowing sinh: they run (heavy class) and leave finite / reference-like output
     pn = [dict(params[0], waveform="Ruído Branco", am_on=False, fm_on=False), dict(params[0], waveform="Seno", am_on=False, fm_on=False)]
     mag2, pb2, pm2, y2 = S.synth_analyze(pn, None, n_base, 8, "hann", return_signal=True)
