@@ -125,7 +125,9 @@ int sa_comm_gather_peaks_dev(sa_comm* comm, const int32_t* peak_bin, const float
  *   mag       [batch][n/2+1]    |Y| (or dB), only if SA_F_WRITE_MAG; may be NULL otherwise
  *   peak_bin  [batch]           argmax_k |Y[k]|, lowest k on ties (np.argmax semantics)
  *   peak_mag  [batch]           |Y[peak_bin]| (always linear)
- * n: power of two >= 16.  n <= 32768 (f32) / 16384 (f64) run in ONE LDS-resident pass.  Longer frames, up to 2^29
+ * n: power of two >= 16.  n <= 32768 (f32) / 16384 (f64) run in ONE LDS-resident pass, and so does the next size
+ *    (65536 f32 / 32768 f64: one kernel, two LDS-resident halves) when frames start on even sample boundaries.
+ *    Longer frames, up to 2^29
  *    (the late forks transform up to 1 000 000 points, sab10.py:43, 644), take the multi-pass path: a real-input
  *    four-step in the frame's own arithmetic (window fused into the first pass, |Y| / dB / peak into the last); it
  *    borrows one work buffer from the library, and the *_dev forms then synchronise `stream` before returning.
