@@ -120,9 +120,10 @@ struct FftTail4_16384 {
     static constexpr int TAB = 15 * 64;  // float2 elements: w_1024^(m k), m = tl % 64, [k][m]
     float2 w0;                           // w_16384^tl
     const float2* tab;
-    __device__ __forceinline__ void load(const float2* __restrict__ twR, int tl, float2* lds_tab) {
-        w0 = twR[tl & (TPF - 1)];
-        if (tl < TAB) lds_tab[tl] = twR[(16 * (tl & 63) * ((tl >> 6) + 1)) & (R - 1)];
+    // twR: w_16384^e at twR[stride e] (stride 2: every other entry of a w_32768 table, rfft_split2.h)
+    __device__ __forceinline__ void load(const float2* __restrict__ twR, int tl, float2* lds_tab, int stride = 1) {
+        w0 = twR[stride * (tl & (TPF - 1))];
+        if (tl < TAB) lds_tab[tl] = twR[stride * ((16 * (tl & 63) * ((tl >> 6) + 1)) & (R - 1))];
         tab = lds_tab + (tl & 63);
     }
     // one pad element per 64: the third pass' gather has its lanes 65 elements apart (a half-wave covers the banks once)

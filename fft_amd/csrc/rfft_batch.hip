@@ -210,7 +210,7 @@ template <typename T> static int launch_split2(const RfftArgs<T>& a, hipStream_t
     static_assert(lds <= 160 * 1024, "half transform does not fit LDS");
     static thread_local uint64_t attr_devs = 0;
     SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(rfft_split2_kernel<T, LR>), lds, &attr_devs));
-    const int64_t cap = grid_cap(32, "GENERIC");
+    const int64_t cap = grid_cap(2, "GENERIC");
     hipLaunchKernelGGL((rfft_split2_kernel<T, LR>), dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3((1 << LR) / 16), lds, st, a);
     SA_HIP(hipGetLastError());
     return SA_OK;
@@ -267,7 +267,22 @@ int rfft_peak_strided_dev(const T* x, int64_t batch, int64_t frame_stride, int32
     a.db_floor = sizeof(T) == 8 ? (T)SA_DB_FLOOR_F64 : (T)SA_DB_FLOOR_F32;
     a.win_sym = p->win_sym;
     a.unaligned = (a.frame_stride % 2) != 0 || (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T))) != 0;
-    if (f64_15) return launch_split2<T>(a, st);
+    if (f64_15) {
+        if constexpr (sizeof(T) == 4) {
+            // SA_SPLIT2_T4=0 (A/B aid): the general four-pass plan per half instead of the tail-folded transform
+            static const bool t4 = getenv("SA_SPLIT2_T4") ? atoi(getenv("SA_SPLIT2_T4")) != 0 : true;
+            if (t4) {
+                constexpr int lds = rsplit2_t4_lds_bytes();
+                static thread_local uint64_t attr_devs = 0;
+                SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(rfft_split2_t4_kernel), lds, &attr_devs));
+                const int64_t cap = grid_cap(2, "GENERIC");      // one workgroup fills a CU: few, long-lived ones (2.41 -> 2.52 TB/s)
+                hipLaunchKernelGGL(rfft_split2_t4_kernel, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(1024), lds, st, a);
+                SA_HIP(hipGetLastError());
+                return SA_OK;
+            }
+        }
+        return launch_split2<T>(a, st);
+    }
     return dispatch_generic<T>(log2n, a, st);
 }
 
