@@ -451,6 +451,25 @@ def test_rfft_f32_65536_split_kernel(win):
             np.testing.assert_allclose(pm[:4], pmref[:4], rtol=1e-4)
 
 
+def test_rfft_f32_65536_more_frames_than_workgroups():
+    """The split kernel runs at most two workgroups per CU (512 on an MI355X), each looping over frames: 1027 frames, built
+    from 13 distinct ones, must repeat bit for bit through the loop (LDS legs, tables and peak scratch are reused), and match
+    the oracle."""
+    import fft_amd
+    n, distinct, batch = 65536, 13, 1027
+    rng = np.random.default_rng(65536)
+    t = np.arange(n)
+    base = (rng.standard_normal((distinct, n)) + 2.0 * np.sin(2 * np.pi * rng.uniform(5, n / 2 - 5, (distinct, 1)) * t / n)).astype(np.float32)
+    x = base[np.arange(batch) % distinct]
+    mag, pb, pm = fft_amd.rfft_peak(x, "hann")
+    mref, pbref, _ = O.rfft_mag_peak(base, "hann")
+    assert rel_l2(mag[:distinct], mref).max() < 1e-5 * 16
+    check_peaks(pb[:distinct], pm[:distinct], mref, pbref, False)
+    for i in range(distinct, batch):
+        assert pb[i] == pb[i % distinct] and pm[i] == pm[i % distinct]
+        assert np.array_equal(mag[i], mag[i % distinct]), i
+
+
 @pytest.mark.parametrize("win", ["none", "hann", "gaussian"])
 def test_rfft_f64_32768_single_pass_kernel(win):
     """fp64 frames of 32768 points: one kernel, two 8192-point halves through LDS (rfft_split2.h).  Same bars as every
