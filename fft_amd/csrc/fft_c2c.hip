@@ -58,6 +58,9 @@ struct C2cArgs {
     int conj_out;     // inverse transform: conjugate on store (last pass)
     double scale;     // 1/n for the inverse, else 1
     int natural;      // final pass: 1 = natural order, 0 = leave digit-reversed
+    // final pass on a SLICE of k1 (rows k1 in [slOff, slOff + R1) of slR1; in points at the slice): the natural index of
+    // local row (k1', k2) is slOff + k1' + slR1 k2 + Aglob k3.  slR1 = 0: no slicing.
+    int64_t slR1, slOff, Aglob;
     // ---- distributed four-step (dist_fft.hip) ----
     int64_t tw_col0;  // strided pass: global column index of local column 0 (the twiddle is w^{(tw_col0 + s) k})
     int nt_hint;      // -1: streaming passes chosen from n * batch; 0 / 1: forced
@@ -82,7 +85,8 @@ constexpr int PUSH_TAB_MAX = 16;      // owners a push pass can address (= SA_DI
 //   counter.  With one 128 KiB workgroup per CU nothing else covers the latency of 1024 x 128-byte reads 16 MiB
 //   apart: timing-only variants put that pass at 9.1 ms without the transform and 12.3 ms with it, while the
 //   second pass (rows 16 KiB apart) hides the same transform completely.
-template <int LR, int B, bool FAR, bool STREAM = false, int XF = XF_PLAIN>
+// STREAM: bit 0 = nontemporal loads, bit 1 = nontemporal stores
+template <int LR, int B, bool FAR, int STREAM = 0, int XF = XF_PLAIN>
 __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pass(C2cArgs a) {
     using PL = FftPlan<LR, C2C_PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
 #pragma unroll
                 for (int n1 = 0; n1 < R0; ++n1) {
                     const int64_t rs = (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S;
-                    d[u * R0 + n1] = ld_c<STREAM>(&src[(rs >> a.blk_shift) * a.blk_pitch + (rs & a.blk_mask)]);
+                    d[u * R0 + n1] = ld_c<(STREAM & 1) != 0>(&src[(rs >> a.blk_shift) * a.blk_pitch + (rs & a.blk_mask)]);
                 }
             return;
         }
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) d[u * R0 + n1] = ld_c<STREAM>(&a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S]);
+            for (int n1 = 0; n1 < R0; ++n1) d[u * R0 + n1] = ld_c<(STREAM & 1) != 0>(&a.in[base + (int64_t)(n1 * (R / R0) + tl + TPF * u) * a.S]);
     };
     if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x, v);
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -173,8 +177,8 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
             }
             const int k = k0 + TPF * u;
             const Cd z = cmul(smem[c * LDSF + lds_pad<S>(k)], w);
-            if (XF == XF_PUSH) st_c<STREAM>(ptab[k >> a.push_shift] + (int64_t)(k & a.push_mask) * a.push_row + sc, z);
-            else st_c<STREAM>(&outp[(int64_t)k * a.S], z);
+            if (XF == XF_PUSH) st_c<(STREAM & 2) != 0>(ptab[k >> a.push_shift] + (int64_t)(k & a.push_mask) * a.push_row + sc, z);
+            else st_c<(STREAM & 2) != 0>(&outp[(int64_t)k * a.S], z);
         }
         if (FAR) {
 #pragma unroll
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__((FftPlan<LR, C2C_PP>::TPF * B)) c2c_strided_pa
 }
 
 // ---- final (contiguous rows) pass ------------------------------------------------------------------
-template <int LR, int B, int PP = C2C_PP, bool STREAM = false>
+template <int LR, int B, int PP = C2C_PP, int STREAM = 0>
 __global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * B)) c2c_final_pass(C2cArgs a) {
     using PL = FftPlan<LR, PP>;
     constexpr int R = PL::R, P = PL::P, TPF = PL::TPF, R0 = PL::radix(0);
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * B)) c2c_final_pass(C2c
 #pragma unroll
         for (int u = 0; u < P / R0; ++u)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; ++n1) v[u * R0 + n1] = ld_c<STREAM>(&src[n1 * (R / R0) + tl + TPF * u]);
+            for (int n1 = 0; n1 < R0; ++n1) v[u * R0 + n1] = ld_c<(STREAM & 1) != 0>(&src[n1 * (R / R0) + tl + TPF * u]);
     };
     if ((int64_t)blockIdx.x < ngroups) load_group(blockIdx.x);
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -226,8 +230,9 @@ __global__ void __launch_bounds__((FftPlan<LR, PP>::TPF * B)) c2c_final_pass(C2c
             Cd z = smem[c * LDSF + lds_pad<S>(k)];
             z.x *= a.scale; z.y *= a.scale;
             if (a.conj_out) z.y = -z.y;
-            const int64_t o = a.natural ? (r0 + c) + a.A * (int64_t)k : (r0 + c) * R + k;
-            st_c<STREAM>(&a.out[b * a.n + o], z);
+            int64_t o = a.natural ? (r0 + c) + a.A * (int64_t)k : (r0 + c) * R + k;
+            if (a.slR1) o = a.slOff + (r0 % a.R1) + c + a.slR1 * (r0 / a.R1) + a.Aglob * (int64_t)k;   // B divides the slice's R1
+            st_c<(STREAM & 2) != 0>(&a.out[b * a.n + o], z);
         }
         __syncthreads();
     }
@@ -247,7 +252,7 @@ static const Cd* tw_table(int64_t n, int64_t count, int64_t stride) {
     return static_cast<const Cd*>(get_cached_table(key, (size_t)count * 16, fill_tw, &c));
 }
 
-template <int LR, int B, bool FAR = false, bool NT = false, int XF = XF_PLAIN>
+template <int LR, int B, bool FAR = false, int NT = 0, int XF = XF_PLAIN>
 static int launch_strided(C2cArgs a, hipStream_t st) {
     constexpr int lds = lds_fft_elems<double, LR>() * B * 16 + (FAR ? (16 << LR) : 0) + (XF == XF_PUSH ? PUSH_TAB_MAX * 8 : 0);
     static_assert(lds <= 160 * 1024, "strided pass does not fit LDS");
@@ -260,7 +265,7 @@ static int launch_strided(C2cArgs a, hipStream_t st) {
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
-template <int LR, int B, int PP = C2C_PP, bool NT = false>
+template <int LR, int B, int PP = C2C_PP, int NT = 0>
 static int launch_final(C2cArgs a, hipStream_t st) {
     constexpr int lds = lds_fft_elems<double, LR>() * B * 16;
     auto kern = c2c_final_pass<LR, B, PP, NT>;
@@ -289,11 +294,11 @@ static int run_strided(int lr, const C2cArgs& a, hipStream_t st) {
     static const int far_env = getenv("SA_C2C_FAR") ? atoi(getenv("SA_C2C_FAR")) : 3;
     const int far = a.batch * a.A * (a.S / 8) >= 8 * (int64_t)num_cus() ? far_env : 0;
     if (c2c_stream_nt(a)) {
-        if (lr == 10 && (far & 1)) return launch_strided<10, 8, true, true>(a, st);
+        if (lr == 10 && (far & 1)) return launch_strided<10, 8, true, 3>(a, st);
         // SA_C2C_B16 (A/B aid, profiles/r03_c5_split_ab.txt): radix-512 passes take 16 columns per workgroup (256-byte segments)
         static const int b16 = getenv("SA_C2C_B16") ? atoi(getenv("SA_C2C_B16")) : 0;
-        if (lr == 9 && (far & 2) && b16 && a.S % 16 == 0) return launch_strided<9, 16, true, true>(a, st);
-        if (lr == 9 && (far & 2)) return launch_strided<9, 8, true, true>(a, st);
+        if (lr == 9 && (far & 2) && b16 && a.S % 16 == 0) return launch_strided<9, 16, true, 3>(a, st);
+        if (lr == 9 && (far & 2)) return launch_strided<9, 8, true, 3>(a, st);
     }
     if (lr == 10 && (far & 1)) return launch_strided<10, 8, true>(a, st);
     if (lr == 9 && (far & 2)) return launch_strided<9, 8, true>(a, st);
@@ -314,15 +319,15 @@ template <int XF>
 static int run_strided_x(int lr, const C2cArgs& a, hipStream_t st) {
     const bool far = a.batch * a.A * (a.S / 8) >= 8 * (int64_t)num_cus();
     if (far && c2c_stream_nt(a)) {
-        if (lr == 10) return launch_strided<10, 8, true, true, XF>(a, st);
-        if (lr == 9) return launch_strided<9, 8, true, true, XF>(a, st);
+        if (lr == 10) return launch_strided<10, 8, true, 3, XF>(a, st);
+        if (lr == 9) return launch_strided<9, 8, true, 3, XF>(a, st);
     }
     switch (lr) {
-        case 6: return launch_strided<6, 8, false, false, XF>(a, st);
-        case 7: return launch_strided<7, 8, false, false, XF>(a, st);
-        case 8: return launch_strided<8, 8, false, false, XF>(a, st);
-        case 9: return launch_strided<9, 8, false, false, XF>(a, st);
-        case 10: return launch_strided<10, 8, false, false, XF>(a, st);
+        case 6: return launch_strided<6, 8, false, 0, XF>(a, st);
+        case 7: return launch_strided<7, 8, false, 0, XF>(a, st);
+        case 8: return launch_strided<8, 8, false, 0, XF>(a, st);
+        case 9: return launch_strided<9, 8, false, 0, XF>(a, st);
+        case 10: return launch_strided<10, 8, false, 0, XF>(a, st);
     }
     set_error("c2c: internal factor 2^%d unsupported", lr);
     return SA_EUNSUP;
@@ -332,9 +337,9 @@ static int run_final_multi(int lr, const C2cArgs& a, hipStream_t st) {
     // gain nothing from it.  SA_C2C_FINAL_PP16=0 (tuning aid) turns it off.
     static const int pp16 = getenv("SA_C2C_FINAL_PP16") ? atoi(getenv("SA_C2C_FINAL_PP16")) : 1;
     if (c2c_stream_nt(a)) {
-        if (lr == 10 && (pp16 & 1)) return launch_final<10, 8, 16, true>(a, st);
-        if (lr == 9) return launch_final<9, 8, C2C_PP, true>(a, st);
-        if (lr == 11) return launch_final<11, 4, 16, true>(a, st);        // 2048-point rows (SA_C2C_SPLIT experiments only)
+        if (lr == 10 && (pp16 & 1)) return launch_final<10, 8, 16, 3>(a, st);
+        if (lr == 9) return launch_final<9, 8, C2C_PP, 3>(a, st);
+        if (lr == 11) return launch_final<11, 4, 16, 3>(a, st);        // 2048-point rows (SA_C2C_SPLIT experiments only)
     }
     if (lr == 10 && (pp16 & 1) && a.batch * (a.A / 8) >= 8 * (int64_t)num_cus()) return launch_final<10, 8, 16>(a, st);
     switch (lr) {
@@ -422,6 +427,32 @@ int c2c_f64_dev(const double* in, double* out, double* work, int64_t n, int64_t 
         a.twR = tw_table(R2, R2, 1);
         if (!a.twR) return SA_EHIP;
         return run_final_multi(l2, a, st);
+    }
+    // Sliced form (streaming sizes, radix-1024 passes): passes 2 and 3 run slice by slice over k1, SA_C2C_SLICE_MIB of the
+    // work buffer at a time, so that pass 3 reads what pass 2 just wrote out of the 256 MiB MALL instead of HBM: pass 2
+    // then stores with the default policy and pass 3 loads with it (the other two streams stay nontemporal).
+    static const long slice_mib = getenv("SA_C2C_SLICE_MIB") ? atol(getenv("SA_C2C_SLICE_MIB")) : 0;
+    if (slice_mib > 0 && c2c_stream_nt(a) && l2 == 10 && l3 == 10 && batch == 1 && a.natural) {
+        int64_t G = ((int64_t)slice_mib << 20) / (R2 * R3 * 16);
+        if (G < 8) G = 8;
+        while (G & (G - 1)) G &= G - 1;                       // power of two
+        if (G > R1) G = R1;
+        const Cd* tw2 = tw_table(R2, R2, 1);
+        const Cd* tw3 = tw_table(R3, R3, 1);
+        if (!tw2 || !tw3) return SA_EHIP;
+        C2cArgs p2 = a, p3 = a;
+        p2.A = G; p2.S = R3; p2.twR = tw2;
+        SA_TRY(set_pass_twiddles(p2, R2 * R3));
+        p3.A = G * R2; p3.R1 = G; p3.R2 = R2; p3.conj_out = inverse; p3.twR = tw3;
+        p3.slR1 = R1; p3.Aglob = R1 * R2;
+        for (int64_t a0 = 0; a0 < R1; a0 += G) {
+            Cd* sl = reinterpret_cast<Cd*>(work) + a0 * R2 * R3;
+            p2.in = sl; p2.out = sl;
+            SA_TRY((launch_strided<10, 8, true, 1>(p2, st)));          // loads nontemporal, stores cached
+            p3.in = sl; p3.out = reinterpret_cast<Cd*>(out); p3.slOff = a0;
+            SA_TRY((launch_final<10, 8, 16, 2>(p3, st)));              // loads cached, stores nontemporal
+        }
+        return SA_OK;
     }
     // pass 2: [R1][R2][R3], work -> work (in place: a workgroup owns its columns)
     a.in = reinterpret_cast<const Cd*>(work); a.out = reinterpret_cast<Cd*>(work);
