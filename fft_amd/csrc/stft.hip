@@ -35,6 +35,7 @@ struct StftArgs {
     int64_t nframes;        // STFT frames per channel
     int64_t hop;
     const float* win;       // [nfft] or nullptr
+    const float* winq;      // [nfft], window x 1/2 x 1/32768 (never null; stft8192q.h only)
     const float2* twR;      // w_N^i
     int flags;
     float* mag;             // [2][nframes][N/2+1]
@@ -44,6 +45,7 @@ struct StftArgs {
 
 }  // namespace sa
 #include "stft8192.h"      // nfft = 8192: 32 points per thread, two exchanges (uses StftArgs)
+#include "stft8192q.h"     // the same plan as four 35 KiB workgroups per CU (half exchanges, constants from L2)
 namespace sa {
 
 // frames per workgroup: small transforms share a workgroup of >= 256 threads
@@ -330,8 +332,27 @@ static int launch_stft8192(const StftArgs& a, hipStream_t st) {
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
+template <class M>
+static int launch_stft8192q(const StftArgs& a, hipStream_t st) {
+    static thread_local uint64_t attr_devs = 0;
+    const int lds = Stft32Q::LDS_BYTES;
+    SA_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(stft8192q_kernel<M>), lds, &attr_devs));
+    const int64_t cap = (grid_cap(64, "STFT") + 7) / 8 * 8, need = (a.nframes + 7) / 8 * 8;
+    hipLaunchKernelGGL((stft8192q_kernel<M>), dim3((unsigned)(need < cap ? need : cap)), dim3(Stft32Q::T), lds, st, a);
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+// the window (or ones) times the 1/2 of the channel split and the 1/32768 of the PCM scale: exact (a power of two)
+static void fill_win32q(void* host, void* ctx) {
+    WinF32Ctx* c = static_cast<WinF32Ctx*>(ctx);
+    std::vector<double> w;
+    if (c->w == SA_WIN_NONE) w.assign((size_t)c->n, 1.0); else host_window(c->w, c->p, (int)c->n, w);
+    float* o = static_cast<float*>(host);
+    for (size_t i = 0; i < w.size(); ++i) o[i] = (float)w[i] * (0.5f / 32768.0f);
+}
 // SA_STFT_V (A/B aid) for nfft 8192: 0 = the 16-point-per-thread kernel with the folded radix-2 tail (round 2),
-// 1 = 32 points per thread, plain fp32 arithmetic, 2 = the same with packed fp32 arithmetic (default)
+// 1 = 32 points per thread, plain fp32 arithmetic (default), 2 = the same with packed fp32 arithmetic, 3 = two lock-stepped
+// teams per workgroup, 4 = the 32-point plan as four 35 KiB workgroups per CU (half exchanges, stft8192q.h)
 static int stft_version() {
     static const int v = getenv("SA_STFT_V") ? atoi(getenv("SA_STFT_V")) : 1;
     return v;
@@ -390,6 +411,17 @@ int stft_pcm16_dev(const int16_t* pcm, int64_t n_samples, int32_t channels, int3
             case 11: return launch_stereo<11>(a, st);
             case 12: return launch_stereo<12>(a, st);
             case 13:
+                // SA_STFT_V=4: four small workgroups per CU (stft8192q.h).  Measured on C3's recording: 6.2 against 7.0 ms
+                // without the spectrum stores, 8.9 against 7.9 ms with them — and its peak magnitudes differ from the default
+                // kernel's in the last place (other FMA contractions), so it is not chosen by flags: opt-in only.
+                if (stft_version() == 4) {
+                    WinF32Ctx wc{window, win_param, nfft};
+                    char key[96];
+                    snprintf(key, sizeof(key), "win32q:%d:%.17g:%d", window, window_has_param(window) && win_param > 0 ? win_param : 0.0, nfft);
+                    a.winq = static_cast<const float*>(get_cached_table(key, (size_t)nfft * 4, fill_win32q, &wc));
+                    if (!a.winq) return SA_EHIP;
+                    return launch_stft8192q<MathPlain>(a, st);
+                }
                 if (stft_version() == 3) return launch_stft8192<MathPlain, 2>(a, st);   // two lock-stepped teams per workgroup
                 if (stft_version() == 2) return launch_stft8192<MathPk, 1>(a, st);
                 if (stft_version() == 1) return launch_stft8192<MathPlain, 1>(a, st);

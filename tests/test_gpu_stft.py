@@ -155,3 +155,44 @@ def test_sharded_stft_equals_single_pass():
             np.testing.assert_array_equal(np.concatenate([p[2] for p in parts], axis=1), mag)
             np.testing.assert_array_equal(np.concatenate([p[3] for p in parts], axis=1), pb)
             np.testing.assert_array_equal(np.concatenate([p[4] for p in parts], axis=1), pm)
+
+
+def test_stft8192_kernel_variants_agree(tmp_path):
+    """nfft = 8192 has selectable kernels (SA_STFT_V: 0 = 16 points per thread with the folded tail, 1 = 32 points per
+    thread — the default —, 2 = packed arithmetic, 3 = two teams per workgroup, 4 = four 35 KiB workgroups per CU with half
+    exchanges and no launch constants in registers).  The variable is read once per process, so the others run in child
+    processes: same peak bins as the default kernel, spectra within the fp32 bar of the oracle and within a few ulp of
+    the default's (different kernels contract different multiply-add pairs); windows none / Blackman, dB and
+    DC/Nyquist-excluded modes, a frame count that leaves ragged workgroups."""
+    import os
+    import subprocess
+    import sys
+    import fft_amd
+    nfft, hop, nframes = 8192, 2048, 37
+    pcm = synth_pcm((nframes - 1) * hop + nfft + 5, 2, 8192 + 4)
+    np.save(tmp_path / "pcm.npy", pcm)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import fft_amd; pcm = np.load(sys.argv[1]);"
+        "m, pb, pm = fft_amd.stft_pcm16(pcm, 8192, 2048, 'blackman'); n, pbn, _ = fft_amd.stft_pcm16(pcm, 8192, 2048, 'none');"
+        "d, pbd, _ = fft_amd.stft_pcm16(pcm, 8192, 2048, 'blackman', db=True, exclude_dc_nyq=True);"
+        "_, pb0, pm0 = fft_amd.stft_pcm16(pcm, 8192, 2048, 'blackman', write_mag=False);"
+        "np.savez(sys.argv[2], m=m, pb=pb, pm=pm, n=n, pbn=pbn, d=d, pbd=pbd, pb0=pb0, pm0=pm0)" % root)
+    m, pb, pm = fft_amd.stft_pcm16(pcm, nfft, hop, "blackman")
+    n_, pbn, _ = fft_amd.stft_pcm16(pcm, nfft, hop, "none")
+    d, pbd, _ = fft_amd.stft_pcm16(pcm, nfft, hop, "blackman", db=True, exclude_dc_nyq=True)
+    mref, pbref, _ = O.stft_pcm16(pcm, nfft, hop, "blackman")
+    np.testing.assert_array_equal(pb, pbref)
+    for v in ("0", "2", "3", "4"):
+        out = tmp_path / f"v{v}.npz"
+        subprocess.run([sys.executable, "-c", child, str(tmp_path / "pcm.npy"), str(out)], check=True, timeout=200,
+                       env={**os.environ, "SA_STFT_V": v})
+        z = np.load(out)
+        assert rel_l2(z["m"], mref).max() < 1e-5 * 13, v
+        for k, ref in (("pb", pb), ("pbn", pbn), ("pbd", pbd), ("pb0", pb)):
+            np.testing.assert_array_equal(z[k], ref, err_msg=f"SA_STFT_V={v} {k}")
+        np.testing.assert_array_equal(z["pm0"], z["pm"], err_msg=f"SA_STFT_V={v}: peak-only vs spectrum mode of one kernel")
+        np.testing.assert_allclose(z["pm"], pm, rtol=2e-6, err_msg=v)
+        assert rel_l2(z["n"], n_).max() < 2e-6, v
+        loud = d > d.max(axis=-1, keepdims=True) - 80.0            # dB of near-empty bins amplifies the last-place differences
+        assert np.abs(z["d"] - d)[loud].max() < 1e-2, v
