@@ -353,9 +353,9 @@ def secondary_configs(lib, args):
     fails reports {"error": ...}."""
     from tools import bench_legs as L
     return {
-        "c3_stft": L.run_leg(lambda: L.C3(lib, args.c3_log2_samples), 3),
-        "c4_pipeline": L.run_leg(lambda: L.C4(lib, args.c4_batch), 3),
-        "c5_fft_1gpu": L.run_leg(lambda: L.C5(lib, args.c5_log2n), 3),
+        "c3_stft": L.run_leg(lambda: L.C3(lib, args.c3_log2_samples)),
+        "c4_pipeline": L.run_leg(lambda: L.C4(lib, args.c4_batch)),
+        "c5_fft_1gpu": L.run_leg(lambda: L.C5(lib, args.c5_log2n)),
     }
 
 

@@ -23,6 +23,12 @@
 #include "fft_pk.h"
 #include "lds_fft.h"
 
+// cache policy of the spectrum stores (aux operand of the buffer intrinsics; build-time A/B aid: 2 = nontemporal,
+// 1 = sc0, 17 = sc0 sc1).  Measured on C3 (profiles/r03_c3_ab.txt): no policy beats the default.
+#ifndef STFT_ST_AUX
+#define STFT_ST_AUX 0
+#endif
+
 namespace sa {
 
 struct Stft32 {
@@ -46,8 +52,8 @@ struct Stft32Emit {
         const float mL = mag_sqrt(m2.x), mR = mag_sqrt(m2.y);
         const float oL = DB ? 20.0f * log10f(fmaxf(mL, SA_DB_FLOOR_F32)) : mL;
         const float oR = DB ? 20.0f * log10f(fmaxf(mR, SA_DB_FLOOR_F32)) : mR;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oL), rl, voff, soff, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oR), rr, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oL), rl, voff, soff, STFT_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oR), rr, voff, soff, STFT_ST_AUX);
         const bool gl = count & (mL > bl), gr = count & (mR > br);          // bins arrive ascending: '>' keeps the first maximum
         bl = gl ? mL : bl; kl = gl ? q : kl;
         br = gr ? mR : br; kr = gr ? q : kr;
@@ -93,12 +99,19 @@ __global__ void __launch_bounds__(256 * TEAMS, 2) stft8192_kernel(StftArgs a) {
     for (int k = 1; k < 16; ++k) { const float2 t = a.twR[32 * (tid & 15) * k]; tw1[k] = M::make(t.x, t.y); }
     // LDS addresses (16-byte units)
     const int p1 = tid >> 4, c1 = tid & 15;                               // pass 1: pair-row, n_c
-    const int p2 = tid & 15, s2 = tid >> 4;                               // pass 2: pair-row, slot
+    // pass 2: pair-row p2 and slot s2.  The slots are dealt so that a wave holds s2 = {2w, 15 - 2w, 2w + 1, 14 - 2w}: slot s2
+    // owns the lower half of the 32-bin block 32 s2 (its F bins) and the upper half of block 480 - 32 s2 (its G bins), so
+    // with the F / G roles of the slots s2 >= 8 SWAPPED (the writers of exchange 2 swap the two halves of their units,
+    // a compile-time choice per slot) every store instruction of a wave covers 64 ADJACENT bins = 256 contiguous bytes
+    // instead of four 64-byte pieces whose line partners arrive from another wave eight stores later.
+    const int p2 = tid & 15, g2 = tid >> 4;
+    const int s2 = (g2 & 1) ? 15 - (2 * (g2 >> 2) + ((g2 >> 1) & 1)) : 2 * (g2 >> 2) + ((g2 >> 1) & 1);
     const float4* rd1 = buf + p1 * K::PITCH + c1;                         // + 16 n_b
     float4* wr2 = buf + p1 * K::PITCH + c1;                               // + 16 s
     const float4* rd2 = buf + p2 * K::PITCH + 16 * s2;                    // + n_c
     // final butterflies of this thread: F bins jF + 512 k, G bins jG + 512 k
     int jF = p2 + 32 * s2, jG = 512 - jF;
+    if (s2 >= 8) { jF = 512 - (p2 + 32 * s2); jG = p2 + 32 * s2; }      // swapped roles (pair-row 0 below keeps its own)
     if (p2 == 0) { jF = s2 <= 7 ? 32 * s2 : 496 - 32 * s2; jG = tid == 0 ? 256 : 512 - jF; }
 
     const uint32_t* pcm = reinterpret_cast<const uint32_t*>(a.pcm);
@@ -171,18 +184,21 @@ __global__ void __launch_bounds__(256 * TEAMS, 2) stft8192_kernel(StftArgs a) {
         // exchange 2: slot s carries (input of F, input of G) of the pass-2 thread (s, p)
         if (wave == 0) {
             // lanes 0..15 hold p = 0 (k_a = 0 and 16, each its own partner): slot 0 = (A0, A8), slots 1..7 = (A[s], A[16-s]),
-            // slots 8..15 = (B[15-s], B[s]); the other lanes of the wave write the common pattern (A[s], B[15-s])
+            // slots 8..15 = (B[15-s], B[s]); the other lanes of the wave write the common pattern (A[s], B[15-s]) — halves
+            // swapped for the slots s >= 8, whose readers run with the F / G roles exchanged
             const bool z = tid < 16;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const C f0 = A[s], g0 = B[15 - s];
+                const C f0 = s <= 7 ? A[s] : B[15 - s], g0 = s <= 7 ? B[15 - s] : A[s];
                 const C f1 = s <= 7 ? A[s] : B[15 - s];
                 const C g1 = s == 0 ? A[8] : s <= 7 ? A[16 - s] : B[s];
                 wr2[16 * s] = make_float4(z ? f1.x : f0.x, z ? f1.y : f0.y, z ? g1.x : g0.x, z ? g1.y : g0.y);
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) wr2[16 * s] = make_float4(A[s].x, A[s].y, B[15 - s].x, B[15 - s].y);
+            for (int s = 0; s < 8; ++s) wr2[16 * s] = make_float4(A[s].x, A[s].y, B[15 - s].x, B[15 - s].y);
+#pragma unroll
+            for (int s = 8; s < 16; ++s) wr2[16 * s] = make_float4(B[15 - s].x, B[15 - s].y, A[s].x, A[s].y);
         }
         __syncthreads();
         // ---- pass 2: F = Z[jF + 512 k], G = Z[jG + 512 k] ------------------------------------------------------------------

@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(256, 4) stft8192q_kernel(StftArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         bfly16m<M>(F);
         bfly16m<M>(G);
+        // (the natural slot order: with stft8192.h's 256-byte-contiguous dealing this shape measured 9.8 ms instead of 8.9)
         const int p2 = tq & 15, s2 = tq >> 4;
         int jF = p2 + 32 * s2, jG = 512 - jF;
         if (p2 == 0) { jF = s2 <= 7 ? 32 * s2 : 496 - 32 * s2; jG = tq == 0 ? 256 : 512 - jF; }

@@ -241,14 +241,17 @@ class C5:
             b.free()
 
 
-def run_leg(make, iters=3):
-    """Build a leg, time it, check it, free it.  Never raises: a failure comes back as {"error": ...} so that the
-    caller's headline line survives."""
+def run_leg(make, iters=10, warm=3):
+    """Build a leg, time it (`warm` untimed launches, then the average of `iters` back-to-back ones — the same steady-state
+    rule as the headline's warm-up + steps; the clock of an idle part takes a few launches to settle), check it, free it.
+    Never raises: a failure comes back as {"error": ...} so that the caller's headline line survives."""
     leg = None
     try:
         leg = make()
-        ms = timed(leg.lib, leg.run, iters)
+        ms = timed(leg.lib, leg.run, iters, warm)
         out = leg.result(ms)
+        out["timed_launches"] = iters
+        out["warmup_launches"] = warm
         out.update(leg.check())
         return out
     except Exception as e:                                     # noqa: BLE001 — an extra leg must not cost the headline
