@@ -120,6 +120,14 @@ static int launch_r4k(const RfftArgs<float>& a, hipStream_t st) {
     // SA_R4K_WH (tuning aid): 3 = default, 6 = 4-wave one-shot, 0 = the looping 16-wave workgroup.
     static const int wh = getenv("SA_R4K_WH") ? atoi(getenv("SA_R4K_WH")) : 3;
     // (peak-only mode measured 286 M/s in the one-shot form against 291 M/s looping: it stays persistent)
+    if constexpr (MODE == 0) {
+        // SA_R4K_WH_B = 3 | 4 (A/B aid): the peak-only mode in the one-shot form as well
+        static const int whb = getenv("SA_R4K_WH_B") ? atoi(getenv("SA_R4K_WH_B")) : 0;
+        if (whb && a.win_sym && r4k_nt()) {
+            if (whb == 3) return launch_r4k_v<0, 3, false, 0, R4K_NT_STREAM, 3>(a, st);
+            if (whb == 4) return launch_r4k_v<0, 4, false, 0, R4K_NT_STREAM, 3>(a, st);
+        }
+    }
     if constexpr (MODE != 0) {
         if (a.win_sym && r4k_nt()) {
             if (wh == 3) return launch_r4k_v<MODE, 3, false, 0, R4K_NT_STREAM, 3>(a, st);
