@@ -39,6 +39,11 @@ constexpr int r4k_wtab_bytes(bool half) { return half ? 2048 * 4 : 4096 * 4; }
 #define R4K_TW2_TABLE 1
 #endif
 constexpr int R4K_TW2_BYTES = R4K_TW2_TABLE ? 8 * 17 * 8 : 0;
+// peak-only mode: skip the Hermitian pairs that cannot hold the frame's peak (see PRUNE in the kernel).  R4K_PRUNE=0
+// (build-time A/B aid) evaluates every pair.
+#ifndef R4K_PRUNE
+#define R4K_PRUNE 1
+#endif
 constexpr int r4k_lds_bytes(int waves, bool half = false) { return r4k_wtab_bytes(half) + waves * R4K_SLAB_BYTES + 6 * 64 * 8 + R4K_TW2_BYTES; }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -98,9 +103,9 @@ __device__ __forceinline__ void stage_fence() { __builtin_amdgcn_sched_barrier(0
 template <int I> __device__ __forceinline__ float2 mul_w16(float2 a) {
     constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
     if constexpr (I == 0) return a;
-    else if constexpr (I == 1) return cmul(a, mk<float>(c1, -s1));
+    else if constexpr (I == 1) return mk<float>(__builtin_fmaf(a.x, c1, a.y * s1), __builtin_fmaf(a.y, c1, -(a.x * s1)));
     else if constexpr (I == 2) return mk<float>((a.x + a.y) * h, (a.y - a.x) * h);
-    else return cmul(a, mk<float>(s1, -c1));
+    else return mk<float>(__builtin_fmaf(a.x, s1, a.y * c1), __builtin_fmaf(a.y, s1, -(a.x * c1)));
 }
 
 __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
@@ -109,14 +114,17 @@ __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sq
 // Returns |X[k]| in ma and |X[2048-k]| in mb.
 // SQ: leave the squares (peak-only mode orders bins by |X|^2 — the square root is monotone — and takes ONE root, of the
 // winner; 32 quarter-rate v_sqrt per lane and frame were 6 % of that mode's issue slots).
+// (The multiply-adds are written as explicit fma calls: left to the compiler, the contraction of a * b + c * d depends on
+// the code around it, and the peak-only mode — whose pairs sit under wave-uniform branches — then differed from the
+// spectrum-writing modes in the last place of the peak magnitude.)
 template <bool SQ = false>
 __device__ __forceinline__ void herm_pair(float2 zq, float2 zm, float2 tw, float& ma, float& mb) {
     const float2 e = mk<float>(zq.x + zm.x, zq.y - zm.y);
     const float2 d = mk<float>(zq.x - zm.x, zq.y + zm.y);
     const float2 o = mk<float>(d.y, -d.x);
-    const float2 wo = cmul(o, tw);
+    const float2 wo = mk<float>(__builtin_fmaf(o.x, tw.x, -(o.y * tw.y)), __builtin_fmaf(o.x, tw.y, o.y * tw.x));
     const float2 xa = cadd(e, wo), xb = csub(e, wo);
-    const float sa_ = xa.x * xa.x + xa.y * xa.y, sb_ = xb.x * xb.x + xb.y * xb.y;
+    const float sa_ = __builtin_fmaf(xa.x, xa.x, xa.y * xa.y), sb_ = __builtin_fmaf(xb.x, xb.x, xb.y * xb.y);
     ma = SQ ? sa_ : fast_sqrt(sa_);
     mb = SQ ? sb_ : fast_sqrt(sb_);
 }
@@ -369,6 +377,17 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
             if (MODE != 0 || (FUSE & 2)) slabf[(kbase + o) + koff] = v;
         };
         const float2 z0 = P1[0];
+        // PRUNE (peak-only mode): a Hermitian pair (zq, zm) yields |X[k]|^2 and |X[2048-k]|^2 = P -+ Q with
+        // P = |zq + conj zm|^2 + |zq - conj zm|^2 = 2 (|zq|^2 + |zm|^2) and |Q| <= P, so the larger of the two lies in [P, 2 P].
+        // The wave first takes s = |zq|^2 + |zm|^2 of its 1024 pairs (4 instructions each) and their maximum; a pair whose
+        // 2 s is below that maximum cannot hold the frame's peak — not even tie with it — and its butterfly, magnitudes and
+        // key updates (~30 instructions, most of them slow forms) are skipped, a whole wave at a time (ballot).  On tone-like
+        // frames a wave runs one or two of its sixteen pair steps; on flat spectra it runs them all, as before.  The 0.1 %
+        // margin covers the rounding of either side (1e-6); NaN makes every comparison fail towards "run it".
+        constexpr bool PRUNE = SQ && R4K_PRUNE;
+        float smax = 0.f;
+        auto psq = [](float2 a, float2 b) { return a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y; };
+        auto live = [&](float sj) { return !PRUNE || __builtin_amdgcn_ballot_w64(!(sj * 2.002f < smax)) != 0ull; };
         {
             const float2 wA = ctab[3 * 64 + l3], wB = ctab[4 * 64 + l3];
             float2 U[8], V[8];
@@ -382,15 +401,35 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
             V[1] = special ? P1[5] : Q1[1]; V[0] = special ? P1[4] : Q1[0];
             // tw_i = w_4096^{k_i};  i >= 4: w16^i = -i * w16^{i-4}.  Twiddles are derived pair by pair so
             // only one (tA, tB) couple is live at a time.
+            float s1a[4], s1b[4];
+            if constexpr (PRUNE) {
+                // (integer maximum of the bit patterns — sums of squares are never negative: a NaN among them comes out on
+                // top and disables the pruning, an infinity keeps only the pairs that reach it)
+                unsigned su = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s1a[i] = psq(U[i], V[7 - i]); s1b[i] = psq(U[i + 4], V[3 - i]);
+                    su = max(su, max(__float_as_uint(s1a[i]), __float_as_uint(s1b[i])));
+                    su = max(su, max(__float_as_uint(psq(P2[i], Q2[7 - i])), __float_as_uint(psq(P2[i + 4], Q2[3 - i]))));
+                }
+                smax = wave_max_f32(__uint_as_float(su));
+            }
             auto slot1 = [&](auto I) {
                 constexpr int i = decltype(I)::value;
                 float ma, mb;
-                herm_pair<SQ>(U[i], V[7 - i], mul_w16<i>(wA), ma, mb);
-                emit(ma, kA, 256 * i);                       // k = kA + 256 i ; 2048 - k = kAm + 256 (7 - i)
-                emit(mb, kAm, 256 * (7 - i));
-                herm_pair<SQ>(U[i + 4], V[3 - i], mul_mi(mul_w16<i>(wB)), ma, mb);
-                emit(ma, kB, 256 * i);                       // buffer voffsets must stay non-negative
-                emit(mb, kBm, 256 * (3 - i));
+                if (live(PRUNE ? s1a[i] : 0.f)) {
+                    herm_pair<SQ>(U[i], V[7 - i], mul_w16<i>(wA), ma, mb);
+                    emit(ma, kA, 256 * i);                   // k = kA + 256 i ; 2048 - k = kAm + 256 (7 - i)
+                    emit(mb, kAm, 256 * (7 - i));
+                }
+                if (live(PRUNE ? s1b[i] : 0.f)) {
+                    herm_pair<SQ>(U[i + 4], V[3 - i], mul_mi(mul_w16<i>(wB)), ma, mb);
+                    // lane 0, i = 3: the pair (Z[1024], Z[1024]) — both results are bin 1024, from two formulas that may round
+                    // apart; the row keeps the second, so the key must not see the first (peak == its own spectrum)
+                    if constexpr (i == 3) ma = special ? mb : ma;
+                    emit(ma, kB, 256 * i);                   // buffer voffsets must stay non-negative
+                    emit(mb, kBm, 256 * (3 - i));
+                }
             };
             slot1(std::integral_constant<int, 0>{}); slot1(std::integral_constant<int, 1>{});
             slot1(std::integral_constant<int, 2>{}); slot1(std::integral_constant<int, 3>{});
@@ -402,12 +441,16 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
                 constexpr int i = decltype(I)::value;
                 const float2 t = mul_w16<i>(wC);
                 float ma, mb;
-                herm_pair<SQ>(P2[i], Q2[7 - i], t, ma, mb);
-                emit(ma, kC, 256 * i);
-                emit(mb, kCm, 256 * (7 - i));
-                herm_pair<SQ>(P2[i + 4], Q2[3 - i], mul_mi(t), ma, mb);
-                emit(ma, kC, 256 * (i + 4));
-                emit(mb, kCm, 256 * (3 - i));
+                if (live(PRUNE ? psq(P2[i], Q2[7 - i]) : 0.f)) {
+                    herm_pair<SQ>(P2[i], Q2[7 - i], t, ma, mb);
+                    emit(ma, kC, 256 * i);
+                    emit(mb, kCm, 256 * (7 - i));
+                }
+                if (live(PRUNE ? psq(P2[i + 4], Q2[3 - i]) : 0.f)) {
+                    herm_pair<SQ>(P2[i + 4], Q2[3 - i], mul_mi(t), ma, mb);
+                    emit(ma, kC, 256 * (i + 4));
+                    emit(mb, kCm, 256 * (3 - i));
+                }
             };
             slot2(std::integral_constant<int, 0>{}); slot2(std::integral_constant<int, 1>{});
             slot2(std::integral_constant<int, 2>{}); slot2(std::integral_constant<int, 3>{});

@@ -215,7 +215,9 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
             const int mlow = lds_pad<S>(TPF - tq);
             constexpr T HALF = HOIST ? (T)1 : (T)0.5;        // fp32: already in the window
             // (zq, zm) = (Z[q], Z[M - q]) and wq = w_N^q give bins q and M - q; DC0: q may be 0 (lane tq == 0)
-            auto pair = [&](C zq, C zm, C wq, int q, auto DC0) {
+            // SELF0: for lane tq == 0 this call is the pair (Z[M/2], Z[M/2]) — both results are bin M/2, from two formulas that
+            // may round apart; the row keeps the second, so the first is replaced by it (peak == its own spectrum)
+            auto pair = [&](C zq, C zm, C wq, int q, auto DC0, auto SELF0) {
                 // E = (Zq + conj(Zm))/2 ; O = -(i/2)(Zq - conj(Zm))
                 const C e0 = mk<T>(HALF * (zq.x + zm.x), HALF * (zq.y - zm.y));
                 const C d = mk<T>(HALF * (zq.x - zm.x), HALF * (zq.y + zm.y));
@@ -232,8 +234,9 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                 }
                 const C xa = cadd(e, wo);            // X[q]
                 const C xb = csub(e, wo);            // conj(X[M-q])
-                const T ma = mag_sqrt(xa.x * xa.x + xa.y * xa.y);
+                T ma = mag_sqrt(xa.x * xa.x + xa.y * xa.y);
                 const T mb = mag_sqrt(xb.x * xb.x + xb.y * xb.y);
+                if constexpr (decltype(SELF0)::value) ma = tq == 0 ? mb : ma;
                 const int ka = q, kb = M - q;
                 if (wmag) { mf[ka] = out(ma); mf[kb] = out(mb); }
                 const bool ga = !(excl && ka == 0) && peak_better(ma, ka, best, best_k);
@@ -263,15 +266,16 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                         const C t = zam;
                         zam.x = z0 ? zb.x : zam.x; zam.y = z0 ? zb.y : zam.y;
                         zb.x = z0 ? t.x : zb.x;    zb.y = z0 ? t.y : zb.y;
-                        pair(za, zam, tn[u], j, std::true_type{});
+                        pair(za, zam, tn[u], j, std::true_type{}, std::false_type{});
+                        pair(zb, zbm, mk<T>(-tn[u].y, -tn[u].x), H - j, std::false_type{}, std::true_type{});
                     } else {
-                        pair(za, zam, tn[u], j, std::false_type{});
+                        pair(za, zam, tn[u], j, std::false_type{}, std::false_type{});
+                        pair(zb, zbm, mk<T>(-tn[u].y, -tn[u].x), H - j, std::false_type{}, std::false_type{});
                     }
-                    pair(zb, zbm, mk<T>(-tn[u].y, -tn[u].x), H - j, std::false_type{});
                 }
                 if (tq == 0) {                                      // butterfly M/4 is its own mirror: bins M/4 and 3M/4
                     const C e = buf[lds_pad_c<S>(H / 2)], o = buf[PLANE + lds_pad_c<S>(H / 2)];
-                    pair(cadd(e, o), csub(e, o), a.twN[H / 2], H / 2, std::false_type{});
+                    pair(cadd(e, o), csub(e, o), a.twN[H / 2], H / 2, std::false_type{}, std::false_type{});
                 }
                 return;
             }
@@ -305,17 +309,18 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                     const C w = tn[u], wc = mk<T>(w.x, -w.y);
                     const C w8w = mk<T>(h * (w.x + w.y), h * (w.y - w.x));           // (h - i h) w
                     const C w8wc = mk<T>(h * (wc.x + wc.y), h * (wc.y - wc.x));      // (h - i h) conj w
-                    if (u == 0) pair(A[0], B[3], w, j, std::true_type{});
-                    else pair(A[0], B[3], w, j, std::false_type{});
-                    pair(A[1], B[2], w8w, j + Q, std::false_type{});
-                    pair(B[1], A[2], mk<T>(-w.y, -w.x), 2 * Q - j, std::false_type{});
-                    pair(B[0], A[3], w8wc, Q - j, std::false_type{});
+                    if (u == 0) pair(A[0], B[3], w, j, std::true_type{}, std::false_type{});
+                    else pair(A[0], B[3], w, j, std::false_type{}, std::false_type{});
+                    pair(A[1], B[2], w8w, j + Q, std::false_type{}, std::false_type{});
+                    if (u == 0) pair(B[1], A[2], mk<T>(-w.y, -w.x), 2 * Q - j, std::false_type{}, std::true_type{});
+                    else pair(B[1], A[2], mk<T>(-w.y, -w.x), 2 * Q - j, std::false_type{}, std::false_type{});
+                    pair(B[0], A[3], w8wc, Q - j, std::false_type{}, std::false_type{});
                 }
                 if (tq == 0) {                                         // butterfly M/8 is its own mirror: bins M/8, 3M/8, 5M/8, 7M/8
                     C A[4];
                     quad(lds_pad_c<S>(Q / 2), A);
-                    pair(A[0], A[3], a.twN[Q / 2], Q / 2, std::false_type{});
-                    pair(A[1], A[2], a.twN[Q / 2 + Q], Q / 2 + Q, std::false_type{});
+                    pair(A[0], A[3], a.twN[Q / 2], Q / 2, std::false_type{}, std::false_type{});
+                    pair(A[1], A[2], a.twN[Q / 2 + Q], Q / 2 + Q, std::false_type{}, std::false_type{});
                 }
                 (void)pe;
                 return;
@@ -327,8 +332,8 @@ rfft_mag_peak_generic(RfftArgs<T> a) {
                 const int m0 = lds_pad_c<S>((M - TPF * u) & (M - 1)) - moff;       // what tq = 0 needs in place of mlow
                 const C zq = pq[lds_pad_c<S>(TPF * u)];
                 const C zm = buf[(tq == 0 ? m0 : mlow) + moff];
-                if (u == 0) pair(zq, zm, tn[u < NTN ? u : 0], q, std::true_type{});
-                else pair(zq, zm, tn[u < NTN ? u : 0], q, std::false_type{});
+                if (u == 0) pair(zq, zm, tn[u < NTN ? u : 0], q, std::true_type{}, std::false_type{});
+                else pair(zq, zm, tn[u < NTN ? u : 0], q, std::false_type{}, std::false_type{});
             }
             if (tq == 0) {                           // bin M/2: X = conj(Z[M/2])
                 const C z = buf[lds_pad_c<S>(M / 2)];

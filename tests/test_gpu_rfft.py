@@ -513,3 +513,26 @@ def test_rfft_f64_32768_single_pass_kernel(win):
         assert np.abs(m - mref[i]).max() / mref[i].max() < 1e-12 and b[0] == pbref[i]
     for b_ in (dx, dm, dpb, dpm):
         b_.free()
+
+
+@pytest.mark.parametrize("dtype,n", [(np.float32, 4096), (np.float32, 8192), (np.float32, 16384), (np.float32, 32768),
+                                     (np.float32, 65536), (np.float32, 1 << 17), (np.float64, 4096), (np.float64, 32768)])
+def test_peak_magnitude_is_the_own_spectrum_value_at_the_self_paired_bin(dtype, n):
+    """Bin n/4 is the packed transform's self-paired bin (Z[M/2] pairs with itself): the tuned and tail-folded kernels form
+    it twice, from two formulas that can round one ulp apart, and the row keeps one of them.  The reported peak magnitude
+    must be that one — peak_mag == mag[peak_bin] bit for bit — also when the peak sits exactly there (round 3: 3 of 2^20
+    benchmark frames, all with their peak at bin 1024, carried the other value)."""
+    import fft_amd
+    rng = np.random.default_rng(n)
+    b = 96 if n > 16384 else 2048 if n == 4096 else 512      # the two values part in well under 1 % of the frames
+    t = np.arange(n)
+    x = np.cos(np.pi * t / 2 + rng.uniform(0, 2 * np.pi, (b, 1))) * rng.uniform(0.5, 1.0, (b, 1)) + 0.01 * rng.standard_normal((b, n))
+    x = x.astype(dtype)
+    for win in ("hann", "none"):
+        mag, pb, pm = fft_amd.rfft_peak(x, win)
+        assert (pb == n // 4).all()
+        np.testing.assert_array_equal(pm, mag[np.arange(b), pb])
+        _, pb0, pm0 = fft_amd.rfft_peak(x, win, write_mag=False)
+        np.testing.assert_array_equal(pb0, pb)
+        if not (dtype == np.float32 and n == 4096):
+            np.testing.assert_array_equal(pm0, pm)       # (the 4096-point peak-only mode orders by |Y|^2: same bin, see above)
