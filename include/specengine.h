@@ -124,7 +124,12 @@ int sa_comm_gather_peaks_dev(sa_comm* comm, const int32_t* peak_bin, const float
  *   x         [batch][n]        real frames
  *   mag       [batch][n/2+1]    |Y| (or dB), only if SA_F_WRITE_MAG; may be NULL otherwise
  *   peak_bin  [batch]           argmax_k |Y[k]|, lowest k on ties (np.argmax semantics)
- *   peak_mag  [batch]           |Y[peak_bin]| (always linear)
+ *   peak_mag  [batch]           |Y[peak_bin]| (always linear); with SA_F_WRITE_MAG and a linear spectrum it is the very
+ *                               value written to mag[peak_bin]
+ *   One documented deviation: WITHOUT SA_F_WRITE_MAG, 4096-point fp32 frames are ordered by |Y|^2 and the root is taken
+ *   of the winner only.  Two bins whose |Y| round to the same float while their squares differ in the last place are a
+ *   tie for np.argmax (lowest k) and not for this mode (larger square); exact ties go to the lowest k in both, and
+ *   tone-like frames never differ (tests/test_gpu_rfft.py: exact-tie known answers in both modes).
  * n: power of two >= 16.  n <= 32768 (f32) / 16384 (f64) run in ONE LDS-resident pass, and so does the next size
  *    (65536 f32 / 32768 f64: one kernel, two LDS-resident halves) when frames start on even sample boundaries.
  *    Longer frames, up to 2^29
