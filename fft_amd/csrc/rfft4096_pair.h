@@ -187,6 +187,7 @@ __device__ __forceinline__ void r4p_wave(char* smem_raw, int slot, const float* 
             emit(ma, kA + 256 * i, std::integral_constant<int, 4 * i>{});
             emit(mb, kAm + 256 * (7 - i), std::integral_constant<int, 4 * i + 1>{});
             herm_pair<false>(U[i + 4], V[3 - i], mul_mi(mul_w16<i>(wB)), ma, mb);
+            if constexpr (i == 3) ma = special ? mb : ma;      // lane 0: the pair (P4, P4), bin 1024 twice — one value (rfft4096.h)
             emit(ma, kB + 256 * i, std::integral_constant<int, 4 * i + 2>{});
             emit(mb, kBm + 256 * (3 - i), std::integral_constant<int, 4 * i + 3>{});
         };
@@ -203,7 +204,7 @@ __device__ __forceinline__ void r4p_wave(char* smem_raw, int slot, const float* 
         }
         m_dc = MODE == 2 ? 20.0f * __log10f(fmaxf(v0, db_floor)) : v0;                // bins 0 and 2048 (lane 0 stages them)
         m_ny = MODE == 2 ? 20.0f * __log10f(fmaxf(v1, db_floor)) : v1;
-        // (lane 0 emits bin 1024 twice, from the pair (P4, P4): the same value to the same place)
+        // (lane 0 emits bin 1024 twice, from the pair (P4, P4): made the same value above, to the same place)
     } else {
         kA = 2 * lane + 1;                                                            // slot-2 form of rfft4096.h: no special lane
         kAm = 255 - 2 * lane;

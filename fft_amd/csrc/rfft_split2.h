@@ -304,6 +304,9 @@ __global__ void __launch_bounds__(1024) rfft_split2_t4_kernel(RfftArgs<float> a)
             pair(A[1], B[2], w8w, false, e_lo[uu][1], e_hi[uu][1]);                // q = j + Q
             pair(B[1], A[2], mk<T>(-w.y, -w.x), false, e_hi[uu][2], e_lo[uu][2]);  // q = 2Q - j: bins M - 2j - 4Q, 2j + 4Q
             pair(B[0], A[3], w8wc, false, e_hi[uu][3], e_lo[uu][3]);               // q = Q - j:  bins M - 2j - 6Q, 2j + 6Q
+            // lane 0, j = 0: the pair (Z[2Q], Z[2Q]) — both results are bin 4Q = M/2, from two formulas that may round one ulp
+            // apart; one value for the row and for the peak (rfft4096.h)
+            if (uu == 0) e_hi[uu][2] = tq == 0 ? e_lo[uu][2] : e_hi[uu][2];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { track(e_lo[uu][k], 2 * j + 2 * Q * k); track(e_hi[uu][k], M - 2 * j - 2 * Q * k); }
         }

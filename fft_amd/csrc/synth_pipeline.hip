@@ -213,13 +213,18 @@ synth_pipeline_kernel(PipeArgs a) {
                 best = g ? m : best; bk = g ? k : bk;
             };
             // (zq, zm) = (Z[q], Z[M - q]) -> bins q and M - q; w = w_n^q
-            auto pair = [&](float2 zq, float2 zm, float2 wq, int q, int voff_q, int soff_q, int voff_m, int soff_m) {
+            // SELF0: for lane tq == 0 this call is the pair (Z[M/2], Z[M/2]) — both results are bin M/2, from two formulas that
+            // may round one ulp apart; one value for the row and for the peak (rfft4096.h)
+            auto pair = [&](float2 zq, float2 zm, float2 wq, int q, int voff_q, int soff_q, int voff_m, int soff_m, auto SELF0) {
                 const float2 e = mk<float>(zq.x + zm.x, zq.y - zm.y);          // the 1/2 is in the window
                 const float2 d = mk<float>(zq.x - zm.x, zq.y + zm.y);
                 const float2 wo = cmul(mk<float>(d.y, -d.x), wq);
                 const float2 xa = cadd(e, wo), xb = csub(e, wo);
-                consider(mag_sqrt(xa.x * xa.x + xa.y * xa.y), q, voff_q, soff_q);
-                consider(mag_sqrt(xb.x * xb.x + xb.y * xb.y), M - q, voff_m, soff_m);
+                float ma = mag_sqrt(xa.x * xa.x + xa.y * xa.y);
+                const float mb = mag_sqrt(xb.x * xb.x + xb.y * xb.y);
+                if constexpr (decltype(SELF0)::value) ma = tq == 0 ? mb : ma;
+                consider(ma, q, voff_q, soff_q);
+                consider(mb, M - q, voff_m, soff_m);
             };
             if constexpr (T2) {
                 // Legs of the final radix-2 butterflies: Z[j] = E[j] + O[j], Z[j + M/2] = E[j] - O[j] (j < M/2).  A thread
@@ -247,13 +252,17 @@ synth_pipeline_kernel(PipeArgs a) {
                         zam.x = z0 ? zb.x : zam.x; zam.y = z0 ? zb.y : zam.y;
                         zb.x = z0 ? t.x : zb.x;    zb.y = z0 ? t.y : zb.y;
                     }
-                    pair(za, zam, tj[u], j, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
-                    pair(zb, zbm, mk<float>(-tj[u].y, -tj[u].x), H - j, (TPF - tq) * 4, (H - TPF * (u + 1)) * 4,
-                         tq * 4, (H + TPF * u) * 4);
+                    pair(za, zam, tj[u], j, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4, std::false_type{});
+                    if (u == 0)
+                        pair(zb, zbm, mk<float>(-tj[u].y, -tj[u].x), H - j, (TPF - tq) * 4, (H - TPF * (u + 1)) * 4,
+                             tq * 4, (H + TPF * u) * 4, std::true_type{});
+                    else
+                        pair(zb, zbm, mk<float>(-tj[u].y, -tj[u].x), H - j, (TPF - tq) * 4, (H - TPF * (u + 1)) * 4,
+                             tq * 4, (H + TPF * u) * 4, std::false_type{});
                 }
                 if (tq == 0) {                                      // butterfly M/4 is its own mirror: bins M/4 and 3M/4
                     const float2 e = buf[lds_pad_c<S>(H / 2)], o = buf[PLANE + lds_pad_c<S>(H / 2)];
-                    pair(cadd(e, o), csub(e, o), a.twN[H / 2], H / 2, 0, (H / 2) * 4, 0, (M - H / 2) * 4);
+                    pair(cadd(e, o), csub(e, o), a.twN[H / 2], H / 2, 0, (H / 2) * 4, 0, (M - H / 2) * 4, std::false_type{});
                 }
                 return;
             }
@@ -272,7 +281,7 @@ synth_pipeline_kernel(PipeArgs a) {
                 const int moff = lds_pad_c<S>(M - TPF * (u + 1));
                 const int m0 = lds_pad_c<S>((M - TPF * u) & (M - 1)) - moff;
                 const float2 zq = pq[lds_pad_c<S>(TPF * u)], zm = buf[(tq == 0 ? m0 : mlow) + moff];
-                pair(zq, zm, HOIST ? tn[u] : tl_[u], q, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4);
+                pair(zq, zm, HOIST ? tn[u] : tl_[u], q, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4, std::false_type{});
             }
             if (tq == 0) {                                  // bin M/2: X = conj(Z[M/2])
                 const float2 z = buf[lds_pad_c<S>(M / 2)];
