@@ -205,17 +205,31 @@ synth_pipeline_kernel(PipeArgs a) {
         const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
             wmag ? a.mag + f * (M + 1) : nullptr, 0, wmag ? (M + 1) * 4 : 0, 0x00020000);   // zero-length: stores dropped
         // dB is a uniform run-time choice: two instantiations of the epilogue behind one scalar branch
+        // Peak trackers.  A thread's bins arrive as monotone sequences (q ascending, M - q descending, ...): one tracker per
+        // sequence then needs ONE compare per bin — '>' keeps the first of equal maxima in an ascending sequence, '>=' takes
+        // the last in a descending one, both the lowest bin — instead of the general (m > best || (m == best && k < bk)) with
+        // its DC / Nyquist test, eleven instructions per bin, a tenth of this kernel's arithmetic.  The trackers are merged
+        // with the general rule once per frame.  NaN never enters (every comparison fails), as before.
+        struct Trk {
+            float b = -1.f;
+            int k = 0x7fffffff;
+            __device__ __forceinline__ void asc(float m, int kk, bool cnt) { const bool g = cnt & (m > b); b = g ? m : b; k = g ? kk : k; }
+            __device__ __forceinline__ void desc(float m, int kk, bool cnt) { const bool g = cnt & (m >= b); b = g ? m : b; k = g ? kk : k; }
+            __device__ __forceinline__ void any(float m, int kk) { const bool g = (m > b) | ((m == b) & (kk < k)); b = g ? m : b; k = g ? kk : k; }
+        };
+        Trk t1, t2, t3, t4;
         auto epilogue = [&](auto DBT) {
             constexpr bool DB = decltype(DBT)::value;
-            auto consider = [&](float m, int k, int voff, int soff) {
+            auto put = [&](float m, int voff, int soff) {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(DB ? 20.f * log10f(fmaxf(m, SA_DB_FLOOR_F32)) : m), mrs, voff, soff, 0);
-                const bool g = !(excl && (k == 0 || k == M)) && (m > best || (m == best && k < bk));
-                best = g ? m : best; bk = g ? k : bk;
             };
             // (zq, zm) = (Z[q], Z[M - q]) -> bins q and M - q; w = w_n^q
             // SELF0: for lane tq == 0 this call is the pair (Z[M/2], Z[M/2]) — both results are bin M/2, from two formulas that
             // may round one ulp apart; one value for the row and for the peak (rfft4096.h)
-            auto pair = [&](float2 zq, float2 zm, float2 wq, int q, int voff_q, int soff_q, int voff_m, int soff_m, auto SELF0) {
+            // QASC: this call's q belongs to an ascending sequence of the thread (tracker tq_; its M - q then descends, tracker
+            // tm_), else the other way round.  cnt: false drops both bins from the peak search (DC / Nyquist excluded).
+            auto pair = [&](float2 zq, float2 zm, float2 wq, int q, int voff_q, int soff_q, int voff_m, int soff_m, auto SELF0,
+                            auto QASC, Trk& tq_, Trk& tm_, bool cnt) {
                 const float2 e = mk<float>(zq.x + zm.x, zq.y - zm.y);          // the 1/2 is in the window
                 const float2 d = mk<float>(zq.x - zm.x, zq.y + zm.y);
                 const float2 wo = cmul(mk<float>(d.y, -d.x), wq);
@@ -223,9 +237,12 @@ synth_pipeline_kernel(PipeArgs a) {
                 float ma = mag_sqrt(xa.x * xa.x + xa.y * xa.y);
                 const float mb = mag_sqrt(xb.x * xb.x + xb.y * xb.y);
                 if constexpr (decltype(SELF0)::value) ma = tq == 0 ? mb : ma;
-                consider(ma, q, voff_q, soff_q);
-                consider(mb, M - q, voff_m, soff_m);
+                put(ma, voff_q, soff_q);
+                put(mb, voff_m, soff_m);
+                if constexpr (decltype(QASC)::value) { tq_.asc(ma, q, cnt); tm_.desc(mb, M - q, cnt); }
+                else { tq_.desc(ma, q, cnt); tm_.asc(mb, M - q, cnt); }
             };
+            const bool c0 = !(excl && tq == 0);                                 // bins 0 and M are lane 0's first pair
             if constexpr (T2) {
                 // Legs of the final radix-2 butterflies: Z[j] = E[j] + O[j], Z[j + M/2] = E[j] - O[j] (j < M/2).  A thread
                 // takes butterflies j = tq + TPF u < M/4 and their mirrors M/2 - j: pair A is q = j with
@@ -252,17 +269,22 @@ synth_pipeline_kernel(PipeArgs a) {
                         zam.x = z0 ? zb.x : zam.x; zam.y = z0 ? zb.y : zam.y;
                         zb.x = z0 ? t.x : zb.x;    zb.y = z0 ? t.y : zb.y;
                     }
-                    pair(za, zam, tj[u], j, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4, std::false_type{});
+                    // bins j (ascending in u) and M - j (descending); H - j (descending) and H + j (ascending)
+                    pair(za, zam, tj[u], j, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4, std::false_type{},
+                         std::true_type{}, t1, t2, u == 0 ? c0 : true);
                     if (u == 0)
                         pair(zb, zbm, mk<float>(-tj[u].y, -tj[u].x), H - j, (TPF - tq) * 4, (H - TPF * (u + 1)) * 4,
-                             tq * 4, (H + TPF * u) * 4, std::true_type{});
+                             tq * 4, (H + TPF * u) * 4, std::true_type{}, std::false_type{}, t3, t4, true);
                     else
                         pair(zb, zbm, mk<float>(-tj[u].y, -tj[u].x), H - j, (TPF - tq) * 4, (H - TPF * (u + 1)) * 4,
-                             tq * 4, (H + TPF * u) * 4, std::false_type{});
+                             tq * 4, (H + TPF * u) * 4, std::false_type{}, std::false_type{}, t3, t4, true);
                 }
                 if (tq == 0) {                                      // butterfly M/4 is its own mirror: bins M/4 and 3M/4
                     const float2 e = buf[lds_pad_c<S>(H / 2)], o = buf[PLANE + lds_pad_c<S>(H / 2)];
-                    pair(cadd(e, o), csub(e, o), a.twN[H / 2], H / 2, 0, (H / 2) * 4, 0, (M - H / 2) * 4, std::false_type{});
+                    Trk x1, x2;                                     // out of sequence: merged with the general rule below
+                    pair(cadd(e, o), csub(e, o), a.twN[H / 2], H / 2, 0, (H / 2) * 4, 0, (M - H / 2) * 4, std::false_type{},
+                         std::true_type{}, x1, x2, true);
+                    t1.any(x1.b, x1.k); t1.any(x2.b, x2.k);
                 }
                 return;
             }
@@ -281,14 +303,19 @@ synth_pipeline_kernel(PipeArgs a) {
                 const int moff = lds_pad_c<S>(M - TPF * (u + 1));
                 const int m0 = lds_pad_c<S>((M - TPF * u) & (M - 1)) - moff;
                 const float2 zq = pq[lds_pad_c<S>(TPF * u)], zm = buf[(tq == 0 ? m0 : mlow) + moff];
-                pair(zq, zm, HOIST ? tn[u] : tl_[u], q, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4, std::false_type{});
+                pair(zq, zm, HOIST ? tn[u] : tl_[u], q, tq * 4, TPF * u * 4, (TPF - tq) * 4, (M - TPF * (u + 1)) * 4, std::false_type{},
+                     std::true_type{}, t1, t2, u == 0 ? c0 : true);
             }
             if (tq == 0) {                                  // bin M/2: X = conj(Z[M/2])
                 const float2 z = buf[lds_pad_c<S>(M / 2)];
-                consider(2.0f * mag_sqrt(z.x * z.x + z.y * z.y), M / 2, 0, (M / 2) * 4);
+                const float m = 2.0f * mag_sqrt(z.x * z.x + z.y * z.y);
+                put(m, 0, (M / 2) * 4);
+                t1.any(m, M / 2);
             }
         };
         if (wdb) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        t1.any(t2.b, t2.k); t3.any(t4.b, t4.k); t1.any(t3.b, t3.k);
+        best = t1.b; bk = t1.k;
         if constexpr (TPF >= 64) {
             // whole waves per frame: wave maximum, then the lowest bin among the lanes that hold it, on the DPP path.  A lane
             // whose bins were all NaN still carries -1: it enters as 0 with no bin (rfft_generic.h)
