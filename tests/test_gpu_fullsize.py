@@ -113,3 +113,40 @@ def test_c5_full_size_known_answers(legs):
     res = c5.check()
     assert res["parity_sample_ok"] and res["kat_impulse_err"] < 1e-12 and res["kat_tone_err"] < 1e-12, res
     c5.free()
+
+
+def test_c2_full_size_every_frame_both_modes_and_sampled_oracle(legs):
+    """BASELINE config C2 at its full size (2^20 frames x 4096 points, the bench's own device-generated frames): on EVERY
+    frame peak_bin / peak_mag are the lowest arg-max / the maximum of the kernel's own spectrum row, bit for bit (round 3:
+    3 of the 2^20 frames — peak exactly at bin 1024 — once carried the other of two roundings), the peak-only mode names
+    the same bins and magnitudes (its pair pruning skips nothing that matters), and sampled frames meet the oracle."""
+    import torch
+    from fft_amd import _lib
+    from oracle import spectrum_oracle as O
+    L, lib = legs
+    n, batch, nb = 4096, 1 << 20, 2049
+    dx, dm = TorchBuffer(batch * n * 4), TorchBuffer(batch * nb * 4)
+    dpb, dpm, dpb0, dpm0 = (TorchBuffer(batch * 4) for _ in range(4))
+    _lib.check(lib.sa_fill_tone_noise_f32_dev(dx.ptr, batch, n, 100e3, 0x5EED0002, None))
+    _lib.check(lib.sa_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, _lib.F_WRITE_MAG, dm.ptr, dpb.ptr, dpm.ptr, None))
+    _lib.check(lib.sa_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, 0, None, dpb0.ptr, dpm0.ptr, None))
+    _lib.check(lib.sa_sync())
+    mag = dm.view(torch.float32, (batch, nb))
+    pb, pm = dpb.view(torch.int32, (batch,)), dpm.view(torch.float32, (batch,))
+    idx, mx = lowest_argmax_rows(mag)
+    assert int((idx != pb).sum()) == 0
+    assert int((mx != pm).sum()) == 0
+    assert int((dpb0.view(torch.int32, (batch,)) != pb).sum()) == 0
+    assert int((dpm0.view(torch.float32, (batch,)) != pm).sum()) == 0
+    assert int((pb == 1024).sum()) > 100                                  # the self-paired bin does occur as a peak
+    sel = L.sample_indices(batch, 252, 2)
+    xs = np.empty((len(sel), n), np.float32)
+    ms = np.empty((len(sel), nb), np.float32)
+    for i, f in enumerate(sel):
+        dx.download(xs[i], n * 4, int(f) * n * 4)
+        dm.download(ms[i], nb * 4, int(f) * nb * 4)
+    mref, pbref, _ = O.rfft_mag_peak(xs, "hann")
+    assert (np.linalg.norm(ms - mref, axis=1) / np.linalg.norm(mref, axis=1)).max() < 1e-5 * 12
+    assert (pb[torch.from_numpy(sel).cuda()].cpu().numpy() == pbref).all()
+    for b in (dx, dm, dpb, dpm, dpb0, dpm0):
+        b.free()
