@@ -182,6 +182,11 @@ def main():
                                               max(args.steps, 5), C.byref(ms)))
     alg = ALG_BYTES_B if args.peak_only else ALG_BYTES_A
     achieved = alg * batch / (ms.value * 1e-3) / 1e9
+    # mode A's peak records of the whole launch, kept to check mode B against them below (rank 0 only; untimed)
+    pb_a = pm_a = None
+    if rank == 0 and not args.peak_only:
+        pb_a = np.empty(batch, np.int32); dpb.download(pb_a, batch * 4)
+        pm_a = np.empty(batch, np.float32); dpm.download(pm_a, batch * 4)
     # mode B (peak only, SURVEY §8(d) C2: 16 392 B/frame) timed the same way in the same run
     ms_b = C.c_float(0)
     _lib.check(lib.sa_time_rfft_peak_f32_dev(dx.ptr, batch, n, _lib.WIN_HANN, 0.0, 0, None, dpb.ptr, dpm.ptr,
@@ -245,6 +250,13 @@ def main():
                                            "achieved_GBps": achieved_b, "frac": achieved_b / HBM_PEAK_GBS,
                                            "alg_bytes_per_frame": ALG_BYTES_B}},
         }
+        if pb_a is not None:
+            # the peak-only launch ran last: its records against mode A's, every frame, bins and magnitudes
+            pb_b = np.empty(batch, np.int32); dpb.download(pb_b, batch * 4)
+            pm_b = np.empty(batch, np.float32); dpm.download(pm_b, batch * 4)
+            out["extra"]["mode_b_peak_only"]["bins_equal_mode_a"] = bool((pb_a == pb_b).all())
+            out["extra"]["mode_b_peak_only"]["mags_equal_mode_a"] = bool((pm_a == pm_b).all())
+            out["extra"]["mode_b_peak_only"]["frames_compared"] = int(batch)
         if native_gather is not None:
             gathered = native_gather.pop("_bins", None)
             if native_gather.get("ok") and gathered is not None:
