@@ -386,6 +386,7 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
         // margin covers the rounding of either side (1e-6); NaN makes every comparison fail towards "run it".
         constexpr bool PRUNE = SQ && R4K_PRUNE;
         float smax = 0.f;
+        float s1a[4], s1b[4], s2a[4], s2b[4];           // PRUNE: s of the lane's sixteen pairs
         auto psq = [](float2 a, float2 b) { return a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y; };
         auto live = [&](float sj) { return !PRUNE || __builtin_amdgcn_ballot_w64(!(sj * 2.002f < smax)) != 0ull; };
         {
@@ -401,7 +402,6 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
             V[1] = special ? P1[5] : Q1[1]; V[0] = special ? P1[4] : Q1[0];
             // tw_i = w_4096^{k_i};  i >= 4: w16^i = -i * w16^{i-4}.  Twiddles are derived pair by pair so
             // only one (tA, tB) couple is live at a time.
-            float s1a[4], s1b[4];
             if constexpr (PRUNE) {
                 // (integer maximum of the bit patterns — sums of squares are never negative: a NaN among them comes out on
                 // top and disables the pruning, an infinity keeps only the pairs that reach it)
@@ -410,7 +410,8 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
                 for (int i = 0; i < 4; ++i) {
                     s1a[i] = psq(U[i], V[7 - i]); s1b[i] = psq(U[i + 4], V[3 - i]);
                     su = max(su, max(__float_as_uint(s1a[i]), __float_as_uint(s1b[i])));
-                    su = max(su, max(__float_as_uint(psq(P2[i], Q2[7 - i])), __float_as_uint(psq(P2[i + 4], Q2[3 - i]))));
+                    s2a[i] = psq(P2[i], Q2[7 - i]); s2b[i] = psq(P2[i + 4], Q2[3 - i]);
+                    su = max(su, max(__float_as_uint(s2a[i]), __float_as_uint(s2b[i])));
                 }
                 smax = wave_max_f32(__uint_as_float(su));
             }
@@ -441,12 +442,12 @@ rfft4096_wave_kernel(const float* __restrict__ x, int64_t batch, int64_t frame_s
                 constexpr int i = decltype(I)::value;
                 const float2 t = mul_w16<i>(wC);
                 float ma, mb;
-                if (live(PRUNE ? psq(P2[i], Q2[7 - i]) : 0.f)) {
+                if (live(PRUNE ? s2a[i] : 0.f)) {
                     herm_pair<SQ>(P2[i], Q2[7 - i], t, ma, mb);
                     emit(ma, kC, 256 * i);
                     emit(mb, kCm, 256 * (7 - i));
                 }
-                if (live(PRUNE ? psq(P2[i + 4], Q2[3 - i]) : 0.f)) {
+                if (live(PRUNE ? s2b[i] : 0.f)) {
                     herm_pair<SQ>(P2[i + 4], Q2[3 - i], mul_mi(t), ma, mb);
                     emit(ma, kC, 256 * (i + 4));
                     emit(mb, kCm, 256 * (3 - i));
